@@ -1,0 +1,125 @@
+"""Known-answer tests for the CPU oracle.  The reference ships
+no golden vectors ("parity unpinned"): these values are derived by hand from
+/root/reference/src/main.cpp, plus the checkerboard censuses measured with glibc sin."""
+import math
+
+import numpy as np
+import pytest
+
+from chan_vese_amd import synth
+
+
+def test_heaviside_delta_values(oracle):
+    # src/main.cpp:193,209
+    assert oracle.heaviside(0) == 0.5
+    assert oracle.heaviside(1) == pytest.approx(0.75, abs=1e-16)
+    assert oracle.heaviside(-1) == pytest.approx(0.25, abs=1e-16)
+    assert oracle.delta(0) == pytest.approx(1 / math.pi, rel=1e-15)
+    assert oracle.delta(1) == pytest.approx(1 / (2 * math.pi), rel=1e-15)
+    assert oracle.heaviside(3.0, 2.0) == pytest.approx(0.5 + math.atan(1.5) / math.pi, rel=1e-15)
+    assert oracle.delta(3.0, 2.0) == pytest.approx(2 / (math.pi * 13), rel=1e-15)
+
+
+@pytest.mark.parametrize("n,zeros,pos,neg", [(512, 1023, 130565, 130556),
+                                              (2048, 4095, 2095109, 2095100)])
+def test_checkerboard_census(oracle, n, zeros, pos, neg):
+    u = oracle.checkerboard(n, n)
+    assert (u == 0).sum() == zeros and (u == 1).sum() == pos and (u == -1).sum() == neg
+    assert np.all(u[0] == 0) and np.all(u[:, 0] == 0)       # only row 0 / column 0 are exact zeros
+
+
+def test_checkerboard_rounding_noise_lines(oracle):
+    # signs of sin(pi*i/5) on multiples of five are rounding noise
+    u = oracle.checkerboard(300, 2)
+    s1 = u[:, 1] * np.sign(math.sin(math.pi * 1 / 5))
+    assert [s1[5], s1[10], s1[55], s1[110], s1[145], s1[290]] == [1, -1, -1, 1, -1, 1]
+
+
+def test_curvature_ramp_and_constant(oracle):
+    # u(i,j)=j  =>  kappa = [0, 1/sqrt2-1/sqrt1.25, 0, ..., 0, -1/sqrt2]
+    h, w = 6, 9
+    k = oracle.curvature(np.tile(np.arange(w, dtype=np.float64), (h, 1)))
+    expect = np.zeros(w)
+    expect[1] = 1 / math.sqrt(2) - 1 / math.sqrt(1.25)
+    expect[-1] = -1 / math.sqrt(2)
+    assert np.allclose(k, expect[None, :], rtol=0, atol=1e-15)
+    assert np.all(oracle.curvature(np.full((5, 7), 3.25)) == 0)
+    # transposed ramp exercises the y branch
+    kt = oracle.curvature(np.tile(np.arange(w, dtype=np.float64)[:, None], (1, h)))
+    assert np.allclose(kt, expect[:, None], rtol=0, atol=1e-15)
+
+
+def test_curvature_border_level2(oracle):
+    # BORDER_REPLICATE is applied to nx/ny too: kappa_x(i,0) = 0 and kappa_y(0,j) = 0 exactly
+    rng = np.random.default_rng(3)
+    u = rng.normal(size=(7, 11))
+    k = oracle.curvature(u)
+    p = np.pad(u, 1, mode="edge")
+    c = p[1:-1, 1:-1]
+    upx, upy = p[1:-1, 2:] - c, p[2:, 1:-1] - c
+    ucx, ucy = 0.5 * (p[1:-1, 2:] - p[1:-1, :-2]), 0.5 * (p[2:, 1:-1] - p[:-2, 1:-1])
+    nx = upx / np.sqrt(upx * upx + ucx * ucx + 1e-16)
+    ny = upy / np.sqrt(upy * upy + ucy * ucy + 1e-16)
+    assert k[0, 0] == 0.0
+    assert np.array_equal(k[1:, 0], (ny[1:, 0] - ny[:-1, 0]))
+    assert np.array_equal(k[0, 1:], (nx[0, 1:] - nx[0, :-1]))
+
+
+def test_pm_trip_counts(oracle):
+    # src/main.cpp:498 — floating-point loop counter
+    assert [oracle.pm_trip_count(L, T) for L, T in
+            [(.25, 20), (.25, 250), (.25, 100), (.1, 1.5), (.1, 1)]] == [80, 1000, 400, 15, 11]
+
+
+def test_pm_constant_and_rounding(oracle):
+    img = np.full((9, 12), 77, dtype=np.uint8)
+    out = oracle.perona_malik([img], 10, 0.25, 3)[0]
+    assert np.array_equal(out, img)
+    # a single bright pixel diffuses symmetrically and conserves the border rule g=1
+    img = np.zeros((9, 9), dtype=np.uint8)
+    img[4, 4] = 200
+    out, st = oracle.perona_malik([img], 1000, 0.25, 0.25, want_state=True)
+    s = st[0]
+    assert s[4, 4] < 200 and s[3, 4] == s[5, 4] == s[4, 3] == s[4, 5] > 0
+    assert np.array_equal(out[0], np.clip(np.rint(s), 0, 255).astype(np.uint8))
+
+
+def test_mask_uses_float_cast(oracle):
+    u = np.array([[1e-50, -1e-50, 0.0, 2.0, -3.0, 1e-46]])
+    # (float)1e-50 underflows to 0 => not > 0 (src/main.cpp:397-398)
+    assert oracle.mask(u).tolist() == [[0, 0, 0, 1, 0, 0]]
+    assert oracle.mask(u, invert=True).tolist() == [[1, 1, 1, 0, 1, 1]]
+
+
+def test_region_means_simple(oracle):
+    img = np.array([[10, 20], [30, 40]], dtype=np.uint8)
+    u = np.zeros((2, 2))
+    assert oracle.region_mean(img, u, 0) == 25.0 and oracle.region_mean(img, u, 1) == 25.0
+    u = np.array([[1e9, 1e9], [-1e9, -1e9]])
+    assert oracle.region_mean(img, u, 0) == pytest.approx(15.0, abs=1e-6)
+    assert oracle.region_mean(img, u, 1) == pytest.approx(35.0, abs=1e-6)
+
+
+def test_trajectory_disk_512(oracle):
+    """SURVEY.md §4 trajectory (512^2 disk, defaults, tol=0) — also BASELINE config 1."""
+    img = synth.disk(512)
+    u, done, last, tr = oracle.csv_run([img], oracle.checkerboard(512, 512),
+                                       oracle.make_params(tol=0), 100)
+    assert done == 100
+    assert tr[0] == pytest.approx([79.4346, 79.4258, 93.11], rel=1e-4)
+    assert tr[1] == pytest.approx([82.8090, 76.0510, 7.531e4], rel=1e-4)
+    assert tr[2] == pytest.approx([197.1361, 50.0451, 719.7], rel=1e-4)
+    assert tr[99] == pytest.approx([198.5440, 50.0425, 183.72], rel=1e-4)
+    assert np.abs(u).max() == pytest.approx(411.2, rel=1e-4)
+    m = oracle.mask(u).astype(bool)
+    truth = img == 200
+    assert (m & truth).sum() / (m | truth).sum() == 1.0
+
+
+def test_stop_rule_breaks_after_update(oracle):
+    # src/main.cpp:994,1000: u is updated before the break
+    img = synth.disk(64)
+    p = oracle.make_params(tol=1e9)          # huge tolerance => stop after the first step
+    u0 = oracle.checkerboard(64, 64)
+    u, done, last, tr = oracle.csv_run([img], u0, p, 50)
+    assert done == 1 and not np.array_equal(u, u0)
