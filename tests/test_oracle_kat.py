@@ -110,7 +110,7 @@ def test_trajectory_disk_512(oracle):
     assert tr[1] == pytest.approx([82.8090, 76.0510, 7.531e4], rel=1e-4)
     assert tr[2] == pytest.approx([197.1361, 50.0451, 719.7], rel=1e-4)
     assert tr[99] == pytest.approx([198.5440, 50.0425, 183.72], rel=1e-4)
-    assert np.abs(u).max() == pytest.approx(411.2, rel=1e-4)
+    assert np.abs(u).max() == pytest.approx(411.2, rel=2e-4)
     m = oracle.mask(u).astype(bool)
     truth = img == 200
     assert (m & truth).sum() / (m | truth).sum() == 1.0
