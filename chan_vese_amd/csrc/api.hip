@@ -1,0 +1,639 @@
+// api.hip — host side of the C ABI declared in include/chanvese_hip.h.
+// Owns the device buffers, the stream and the launch sequence of one context; never throws.
+#include <limits.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "cvh_internal.h"
+
+struct cvh_context {
+  int h = 0, w = 0, C = 0, device = 0;
+  size_t n = 0;
+  cvh_params p{};
+  hipStream_t stream = nullptr;
+  uint8_t *d_img[CVH_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
+  double *d_u[2] = {nullptr, nullptr};
+  CvhState *d_state = nullptr;
+  CvhState *h_state = nullptr;  // pinned, two slots for pipelined polling
+  double *d_partials = nullptr;
+  int partial_rows = 0;
+  double *d_trace = nullptr;
+  int trace_cap = 0;
+  double *d_pm[2] = {nullptr, nullptr};
+  uint8_t *d_mask = nullptr;
+  bool have_image = false, have_u = false, sums_valid = false, stop_valid = false;
+  double stop_norm = 0.0;  // || (sum_k I_k)/C ||_2
+  double stop_cond_h = 0.0; // staging for the async upload
+  int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
+  int tiles_x = 0, tiles_y = 0;
+  int cur_base = 0;   // buffer that held u when the run counter was last reset
+  int enqueued = 0;   // steps enqueued since then
+  int steps_done = 0; // as of the last sync
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[2] = {nullptr, nullptr};
+  bool timing_open = false;
+  float last_run_ms = 0.f, last_pm_ms = 0.f;
+  char err[512] = {0};
+};
+
+static char g_create_err[512] = "no error";
+
+static int fail(cvh_context *ctx, int code, const char *fmt, ...)
+{
+  char *dst = ctx ? ctx->err : g_create_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail((ctx), CVH_ERR_HIP, "HIP error %d (%s) in %s", (int)e_, hipGetErrorString(e_), \
+                  #call);                                                                      \
+  } while (0)
+
+static bool use_fast(const cvh_context *c)
+{
+  const int m = c->math_mode == CVH_MATH_DEFAULT ? CVH_MATH_STRICT : c->math_mode;
+  return m == CVH_MATH_FAST;
+}
+
+extern "C" const char *cvh_version(void) { return "chanvese_hip 0.1 (gfx950)"; }
+
+extern "C" void cvh_default_params(cvh_params *p)
+{
+  if (!p) return;
+  p->mu = 0.5; p->nu = 0.0; p->dt = 1.0; p->eps = 1.0; p->tol = 0.001;  // src/main.cpp:759-765
+  for (int k = 0; k < CVH_MAX_CHANNELS; ++k) { p->lambda1[k] = 1.0; p->lambda2[k] = 1.0; }
+}
+
+extern "C" int cvh_device_count(int *count)
+{
+  if (!count) return CVH_ERR_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(nullptr, CVH_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return CVH_OK;
+}
+
+extern "C" const char *cvh_last_error(const cvh_context *ctx) { return ctx ? ctx->err : g_create_err; }
+
+static int check_params(cvh_context *ctx, const cvh_params *p, int C)
+{
+  // the reference's range checks, src/main.cpp:795-830
+  if (!(p->dt > 0)) return fail(ctx, CVH_ERR_ARG, "Cannot have negative or zero timestep: %f.", p->dt);
+  if (p->mu < 0) return fail(ctx, CVH_ERR_ARG, "Length penalty parameter cannot be negative: %f.", p->mu);
+  for (int k = 0; k < C; ++k) {
+    if (p->lambda1[k] < 0) return fail(ctx, CVH_ERR_ARG, "The value of lambda1 cannot be negative.");
+    if (p->lambda2[k] < 0) return fail(ctx, CVH_ERR_ARG, "The value of lambda2 cannot be negative.");
+  }
+  return CVH_OK;
+}
+
+extern "C" void cvh_destroy(cvh_context *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < CVH_MAX_CHANNELS; ++k) if (c->d_img[k]) (void)hipFree(c->d_img[k]);
+  for (int k = 0; k < 2; ++k) { if (c->d_u[k]) (void)hipFree(c->d_u[k]); if (c->d_pm[k]) (void)hipFree(c->d_pm[k]); }
+  if (c->d_state) (void)hipFree(c->d_state);
+  if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_trace) (void)hipFree(c->d_trace);
+  if (c->d_mask) (void)hipFree(c->d_mask);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (int k = 0; k < 2; ++k) if (c->evp[k]) (void)hipEventDestroy(c->evp[k]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int create_impl(cvh_context *c)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int k = 0; k < c->C; ++k) HIPCHK(c, hipMalloc((void **)&c->d_img[k], c->n));
+  for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc((void **)&c->d_u[k], c->n * sizeof(double)));
+  HIPCHK(c, hipMalloc((void **)&c->d_state, sizeof(CvhState)));
+  HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_state, 2 * sizeof(CvhState), hipHostMallocDefault));
+  memset(c->h_state, 0, 2 * sizeof(CvhState));
+  cvh_step_grid(c->h, c->w, &c->tiles_x, &c->tiles_y);
+  const int step_blocks = c->tiles_x * c->tiles_y;
+  const int init_blocks = cvh_init_sum_blocks(c->h, c->w);
+  c->partial_rows = step_blocks > init_blocks ? step_blocks : init_blocks;
+  HIPCHK(c, hipMalloc((void **)&c->d_partials, (size_t)c->partial_rows * cvh_nsums(c->C) * sizeof(double)));
+  HIPCHK(c, hipEventCreate(&c->ev0));
+  HIPCHK(c, hipEventCreate(&c->ev1));
+  for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->evp[k], hipEventDisableTiming));
+  snprintf(c->err, sizeof(c->err), "no error");
+  return CVH_OK;
+}
+
+extern "C" int cvh_create(cvh_context **out, int h, int w, int channels, const cvh_params *p, int device)
+{
+  if (!out) return fail(nullptr, CVH_ERR_ARG, "cvh_create: out is NULL");
+  *out = nullptr;
+  if (h <= 0 || w <= 0) return fail(nullptr, CVH_ERR_ARG, "cvh_create: image size must be positive (got %d x %d)", h, w);
+  if (channels != 1 && channels != 3)
+    return fail(nullptr, CVH_ERR_ARG, "cvh_create: channels must be 1 (grayscale) or 3 (colour), got %d", channels);
+  cvh_params def;
+  cvh_default_params(&def);
+  if (!p) p = &def;
+  int rc = check_params(nullptr, p, channels);
+  if (rc != CVH_OK) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, CVH_ERR_HIP, "cvh_create: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, CVH_ERR_ARG, "cvh_create: device %d out of range [0,%d)", device, ndev);
+  cvh_context *c = new (std::nothrow) cvh_context();
+  if (!c) return fail(nullptr, CVH_ERR_NOMEM, "cvh_create: out of host memory");
+  c->h = h; c->w = w; c->C = channels; c->device = device; c->n = (size_t)h * w; c->p = *p;
+  rc = create_impl(c);
+  if (rc != CVH_OK) {
+    snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
+    cvh_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return CVH_OK;
+}
+
+extern "C" int cvh_set_params(cvh_context *c, const cvh_params *p)
+{
+  if (!c || !p) return CVH_ERR_ARG;
+  int rc = check_params(c, p, c->C);
+  if (rc != CVH_OK) return rc;
+  if (p->eps != c->p.eps) c->sums_valid = false;
+  c->p = *p;
+  return CVH_OK;
+}
+
+extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
+{
+  if (!c || !key) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!strcmp(key, "math_mode")) {
+    if (value < 0 || value > 2) return fail(c, CVH_ERR_ARG, "math_mode must be 0, 1 or 2");
+    c->math_mode = (int)value;
+  } else if (!strcmp(key, "finalize")) {
+    if (value != 0 && value != 1) return fail(c, CVH_ERR_ARG, "finalize must be 0 or 1");
+    c->finalize_mode = (int)value;
+  } else if (!strcmp(key, "sync_every")) {
+    if (value < 1) return fail(c, CVH_ERR_ARG, "sync_every must be >= 1");
+    c->sync_every = (int)(value > 1000000 ? 1000000 : value);
+  } else if (!strcmp(key, "trace")) {
+    if (value < 0) return fail(c, CVH_ERR_ARG, "trace capacity must be >= 0");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_trace) { HIPCHK(c, hipFree(c->d_trace)); c->d_trace = nullptr; }
+    c->trace_cap = 0;
+    if (value > 0) {
+      const size_t bytes = (size_t)value * (2 * c->C + 1) * sizeof(double);
+      HIPCHK(c, hipMalloc((void **)&c->d_trace, bytes));
+      HIPCHK(c, hipMemset(c->d_trace, 0, bytes));
+      c->trace_cap = (int)value;
+    }
+  } else {
+    return fail(c, CVH_ERR_ARG, "unknown option \"%s\"", key);
+  }
+  return CVH_OK;
+}
+
+// tol-free part of the stop condition, src/main.cpp:950-959 (zero-initialised accumulator,
+// channels added serially in k, scaled by 1/C, L2 norm with four squares per step).
+static double stop_norm_host(const std::vector<const uint8_t *> &planes, size_t n)
+{
+  const int C = (int)planes.size();
+  const double inv = 1.0 / C;
+  double s = 0;
+  size_t i = 0;
+  auto avg = [&](size_t q) {
+    double a = 0;
+    for (int k = 0; k < C; ++k) a += (double)planes[k][q];
+    return a * inv;
+  };
+  for (; i + 4 <= n; i += 4) {
+    const double v0 = avg(i), v1 = avg(i + 1), v2 = avg(i + 2), v3 = avg(i + 3);
+    s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+  }
+  for (; i < n; ++i) { const double v = avg(i); s += v * v; }
+  return sqrt(s);
+}
+
+extern "C" int cvh_set_image(cvh_context *c, const uint8_t *const *planes)
+{
+  if (!c || !planes) return CVH_ERR_ARG;
+  for (int k = 0; k < c->C; ++k) if (!planes[k]) return fail(c, CVH_ERR_ARG, "cvh_set_image: plane %d is NULL", k);
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int k = 0; k < c->C; ++k)
+    HIPCHK(c, hipMemcpyAsync(c->d_img[k], planes[k], c->n, hipMemcpyHostToDevice, c->stream));
+  std::vector<const uint8_t *> pl(planes, planes + c->C);
+  c->stop_norm = stop_norm_host(pl, c->n);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_image = true;
+  c->stop_valid = true;
+  c->sums_valid = false;
+  return CVH_OK;
+}
+
+extern "C" int cvh_get_image(cvh_context *c, uint8_t *const *planes)
+{
+  if (!c || !planes) return CVH_ERR_ARG;
+  if (!c->have_image) return fail(c, CVH_ERR_STATE, "cvh_get_image: no image set");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int k = 0; k < c->C; ++k) {
+    if (!planes[k]) return fail(c, CVH_ERR_ARG, "cvh_get_image: plane %d is NULL", k);
+    HIPCHK(c, hipMemcpyAsync(planes[k], c->d_img[k], c->n, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CVH_OK;
+}
+
+static int current_buffer(const cvh_context *c) { return (c->cur_base + c->steps_done) & 1; }
+
+static int reset_run_impl(cvh_context *c)
+{
+  // new run: counter and stop flag cleared; the buffer holding u becomes the base
+  c->cur_base = current_buffer(c);
+  c->steps_done = 0;
+  c->enqueued = 0;
+  const int zeros[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(&c->d_state->steps_done, zeros, sizeof(zeros), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CVH_OK;
+}
+
+extern "C" int cvh_reset_run(cvh_context *c)
+{
+  if (!c) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return reset_run_impl(c);
+}
+
+extern "C" int cvh_set_levelset(cvh_context *c, const double *u)
+{
+  if (!c || !u) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->cur_base = 0; c->steps_done = 0; c->enqueued = 0;
+  HIPCHK(c, hipMemcpyAsync(c->d_u[0], u, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_u = true;
+  c->sums_valid = false;
+  return reset_run_impl(c);
+}
+
+extern "C" void cvh_levelset_checkerboard_host(int h, int w, double *u)
+{
+  // src/main.cpp:226-231: sign(sin(pi*i/5) * sin(pi*j/5)), host libm, double
+  const double pi = 3.14159265358979323846;
+  std::vector<double> sj((size_t)w);
+  for (int j = 0; j < w; ++j) sj[j] = sin(pi * j / 5);
+  for (int i = 0; i < h; ++i) {
+    const double si = sin(pi * i / 5);
+    for (int j = 0; j < w; ++j) {
+      const double z = si * sj[j];
+      u[(size_t)i * w + j] = (z == 0) ? 0.0 : (z < 0 ? -1.0 : 1.0);
+    }
+  }
+}
+
+extern "C" int cvh_init_checkerboard(cvh_context *c)
+{
+  if (!c) return CVH_ERR_ARG;
+  std::vector<double> u;
+  try { u.resize(c->n); } catch (...) { return fail(c, CVH_ERR_NOMEM, "cvh_init_checkerboard: out of host memory"); }
+  cvh_levelset_checkerboard_host(c->h, c->w, u.data());
+  return cvh_set_levelset(c, u.data());
+}
+
+extern "C" int cvh_get_levelset(cvh_context *c, double *u)
+{
+  if (!c || !u) return CVH_ERR_ARG;
+  if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_get_levelset: no level set");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(u, c->d_u[current_buffer(c)], c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CVH_OK;
+}
+
+static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
+{
+  memset(a, 0, sizeof(*a));
+  a->u_in = c->d_u[in_buf];
+  a->u_out = c->d_u[in_buf ^ 1];
+  for (int k = 0; k < c->C; ++k) a->img[k] = c->d_img[k];
+  a->st = c->d_state;
+  a->partials = c->d_partials;
+  a->trace = c->d_trace;
+  a->trace_cap = c->trace_cap;
+  a->h = c->h; a->w = c->w;
+  a->tiles_x = c->tiles_x; a->tiles_y = c->tiles_y;
+  a->nparts = c->tiles_x * c->tiles_y;
+  a->fused_finalize = c->finalize_mode == 0;
+  // src/main.cpp:985: dt * (mu*kappa - nu + u_diff/N) evaluates as one addWeighted
+  a->alpha = c->p.mu * c->p.dt;
+  a->beta = (1.0 / c->C) * c->p.dt;
+  a->gamma = -c->p.nu * c->p.dt;
+  a->eps = c->p.eps;
+  for (int k = 0; k < CVH_MAX_CHANNELS; ++k) { a->lambda1[k] = c->p.lambda1[k]; a->lambda2[k] = c->p.lambda2[k]; }
+}
+
+// Makes c1/c2 of the current level set and the stop condition valid on the device.
+static int prepare(cvh_context *c)
+{
+  if (!c->have_image) return fail(c, CVH_ERR_STATE, "no image set (call cvh_set_image first)");
+  if (!c->have_u) return fail(c, CVH_ERR_STATE, "no level set (call cvh_set_levelset or cvh_init_checkerboard first)");
+  if (!c->stop_valid) {
+    // planes changed on the device (Perona-Malik): src/main.cpp:950 uses the smoothed channels
+    std::vector<std::vector<uint8_t>> host(c->C, std::vector<uint8_t>(c->n));
+    std::vector<const uint8_t *> pl;
+    for (int k = 0; k < c->C; ++k) {
+      HIPCHK(c, hipMemcpyAsync(host[k].data(), c->d_img[k], c->n, hipMemcpyDeviceToHost, c->stream));
+      pl.push_back(host[k].data());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stop_norm = stop_norm_host(pl, c->n);
+    c->stop_valid = true;
+  }
+  c->stop_cond_h = c->p.tol * c->stop_norm;  // :959
+  HIPCHK(c, hipMemcpyAsync(&c->d_state->stop_cond, &c->stop_cond_h, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (!c->sums_valid) {
+    CvhStepArgs a;
+    fill_args(c, &a, current_buffer(c));
+    int nparts = 0;
+    HIPCHK(c, cvh_launch_init_sums(a, c->C, use_fast(c), &nparts, c->stream));
+    a.nparts = nparts;
+    HIPCHK(c, cvh_launch_finalize(a, c->C, 1, c->stream));
+    c->sums_valid = true;
+  }
+  return CVH_OK;
+}
+
+static int enqueue_impl(cvh_context *c, int nsteps)
+{
+  for (int s = 0; s < nsteps; ++s) {
+    CvhStepArgs a;
+    fill_args(c, &a, (c->cur_base + c->enqueued) & 1);
+    HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
+    if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
+    c->enqueued++;
+  }
+  return CVH_OK;
+}
+
+extern "C" int cvh_enqueue_steps(cvh_context *c, int nsteps)
+{
+  if (!c || nsteps < 0) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->timing_open) {
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    c->timing_open = true;
+  }
+  int rc = prepare(c);
+  if (rc != CVH_OK) return rc;
+  return enqueue_impl(c, nsteps);
+}
+
+static int absorb_state(cvh_context *c, const CvhState *hs)
+{
+  c->steps_done = hs->steps_done;
+  if (hs->stopped) c->enqueued = hs->steps_done;  // launches past the stop were no-ops
+  return CVH_OK;
+}
+
+extern "C" int cvh_sync(cvh_context *c, int *steps_done_total, double *last_norm, int *stopped)
+{
+  if (!c) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->timing_open) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->timing_open) {
+    HIPCHK(c, hipEventElapsedTime(&c->last_run_ms, c->ev0, c->ev1));
+    c->timing_open = false;
+  }
+  absorb_state(c, &c->h_state[0]);
+  if (steps_done_total) *steps_done_total = c->h_state[0].steps_done;
+  if (last_norm) *last_norm = c->h_state[0].norm;
+  if (stopped) *stopped = c->h_state[0].stopped;
+  return CVH_OK;
+}
+
+extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *last_norm)
+{
+  if (!c) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->have_image) return fail(c, CVH_ERR_STATE, "no image set (call cvh_set_image first)");
+  if (!c->have_u) return fail(c, CVH_ERR_STATE, "no level set (call cvh_set_levelset or cvh_init_checkerboard first)");
+  if (c->timing_open) { int rc0 = cvh_sync(c, nullptr, nullptr, nullptr); if (rc0 != CVH_OK) return rc0; }
+  int rc = reset_run_impl(c);
+  if (rc != CVH_OK) return rc;
+  long remaining = max_steps < 0 ? (long)INT_MAX : (long)max_steps;  // src/main.cpp:890
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  rc = prepare(c);
+  if (rc != CVH_OK) return rc;
+  // Chunks of sync_every launches; the stop flag of chunk k is read back while chunk k+1
+  // is already queued (launches behind a fired stop are no-ops on the device).
+  int slot = 0, pending = -1;
+  bool stopped = false;
+  while (remaining > 0 && !stopped) {
+    const int chunk = (int)(remaining < c->sync_every ? remaining : c->sync_every);
+    rc = enqueue_impl(c, chunk);
+    if (rc != CVH_OK) return rc;
+    remaining -= chunk;
+    HIPCHK(c, hipMemcpyAsync(&c->h_state[slot], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->evp[slot], c->stream));
+    if (pending >= 0) {
+      HIPCHK(c, hipEventSynchronize(c->evp[pending]));
+      stopped = c->h_state[pending].stopped != 0;
+    }
+    pending = slot;
+    slot ^= 1;
+  }
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventElapsedTime(&c->last_run_ms, c->ev0, c->ev1));
+  c->timing_open = false;
+  absorb_state(c, &c->h_state[0]);
+  c->enqueued = c->steps_done;
+  if (steps_done) *steps_done = c->h_state[0].steps_done;
+  if (last_norm) *last_norm = c->h_state[0].norm;
+  return CVH_OK;
+}
+
+extern "C" int cvh_get_means(cvh_context *c, double *c1, double *c2)
+{
+  if (!c || !c1 || !c2) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->timing_open) return fail(c, CVH_ERR_STATE, "cvh_get_means: steps in flight, call cvh_sync first");
+  int rc = prepare(c);
+  if (rc != CVH_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < c->C; ++k) { c1[k] = c->h_state[0].c1[k]; c2[k] = c->h_state[0].c2[k]; }
+  return CVH_OK;
+}
+
+extern "C" int cvh_get_trace(cvh_context *c, double *out, int max_rows, int *rows)
+{
+  if (!c || !out || !rows || max_rows < 0) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int n = c->steps_done < c->trace_cap ? c->steps_done : c->trace_cap;
+  if (n > max_rows) n = max_rows;
+  *rows = n;
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(out, c->d_trace, (size_t)n * (2 * c->C + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return CVH_OK;
+}
+
+extern "C" int cvh_get_stop_condition(cvh_context *c, double *stop_cond)
+{
+  if (!c || !stop_cond) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = prepare(c);
+  if (rc != CVH_OK) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *stop_cond = c->p.tol * c->stop_norm;
+  return CVH_OK;
+}
+
+extern "C" int cvh_get_mask(cvh_context *c, uint8_t *mask, int invert)
+{
+  if (!c || !mask) return CVH_ERR_ARG;
+  if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_get_mask: no level set");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_mask) HIPCHK(c, hipMalloc((void **)&c->d_mask, c->n));
+  HIPCHK(c, cvh_launch_mask(c->d_u[current_buffer(c)], c->d_mask, c->n, invert, c->stream));
+  HIPCHK(c, hipMemcpyAsync(mask, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CVH_OK;
+}
+
+extern "C" int cvh_separate(cvh_context *c, const uint8_t *img3, int invert, uint8_t *selection3)
+{
+  if (!c || !img3 || !selection3) return CVH_ERR_ARG;
+  if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_separate: no level set");
+  HIPCHK(c, hipSetDevice(c->device));
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d_in, c->n * 3));
+  hipError_t e = hipMalloc((void **)&d_out, c->n * 3);
+  if (e != hipSuccess) { (void)hipFree(d_in); return fail(c, CVH_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  int rc = CVH_OK;
+  do {
+    if ((e = hipMemcpyAsync(d_in, img3, c->n * 3, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+    if ((e = cvh_launch_separate(d_in, c->d_u[current_buffer(c)], d_out, c->n, invert, c->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(selection3, d_out, c->n * 3, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(c->stream);
+  } while (0);
+  if (e != hipSuccess) rc = fail(c, CVH_ERR_HIP, "cvh_separate: %s", hipGetErrorString(e));
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+extern "C" int cvh_pm_trip_count(double L, double T)
+{
+  int n = 0;
+  for (double t = 0; t < T; t += L) {  // src/main.cpp:498: the counter itself is a double
+    if (++n == INT_MAX) break;
+    if (!(L > 0)) break;               // L == 0 would never terminate; one step is what T >= L allows
+  }
+  return n;
+}
+
+extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
+{
+  if (!c) return CVH_ERR_ARG;
+  if (!c->have_image) return fail(c, CVH_ERR_STATE, "cvh_perona_malik: no image set");
+  // src/main.cpp:863-867
+  if (L > 0.25 || L < 0)
+    return fail(c, CVH_ERR_ARG, "The Laplacian coefficient in Perona-Malik segmentation must be between 0 and 0.25.");
+  if (T < L)
+    return fail(c, CVH_ERR_ARG, "The segmentation duration must exceed the value of Laplacian coefficient, %f.", L);
+  if (K == 0) return fail(c, CVH_ERR_ARG, "cvh_perona_malik: edge coefficient K must be non-zero");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int trips = cvh_pm_trip_count(L, T);
+  for (int k = 0; k < 2; ++k)
+    if (!c->d_pm[k]) HIPCHK(c, hipMalloc((void **)&c->d_pm[k], c->n * sizeof(double)));
+  CvhPmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.h = c->h; a.w = c->w; a.K2 = K * K; a.L = L;
+  cvh_pm_grid(c->h, c->w, &a.tiles_x, &a.tiles_y);
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  if (trips > 0) {
+    for (int k = 0; k < c->C; ++k) {
+      HIPCHK(c, cvh_launch_pm_load(c->d_img[k], c->d_pm[0], c->n, c->stream));
+      int cur = 0;
+      for (int t = 0; t < trips; ++t) {
+        a.in = c->d_pm[cur]; a.out = c->d_pm[cur ^ 1];
+        HIPCHK(c, cvh_launch_pm_step(a, c->stream));
+        cur ^= 1;
+      }
+      HIPCHK(c, cvh_launch_pm_store(c->d_pm[cur], c->d_img[k], c->n, c->stream));
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventElapsedTime(&c->last_pm_ms, c->ev0, c->ev1));
+  c->stop_valid = false;
+  c->sums_valid = false;
+  return CVH_OK;
+}
+
+extern "C" int cvh_last_run_ms(cvh_context *c, float *ms)
+{
+  if (!c || !ms) return CVH_ERR_ARG;
+  *ms = c->last_run_ms;
+  return CVH_OK;
+}
+
+extern "C" int cvh_last_pm_ms(cvh_context *c, float *ms)
+{
+  if (!c || !ms) return CVH_ERR_ARG;
+  *ms = c->last_pm_ms;
+  return CVH_OK;
+}
+
+extern "C" int cvh_ppf_apply_device(double *d_data, long n, int op, double eps, void *stream)
+{
+  if (!d_data || n < 0 || op < 0 || op > 2) return fail(nullptr, CVH_ERR_ARG, "cvh_ppf_apply_device: bad argument");
+  hipError_t e = cvh_launch_ppf(d_data, (size_t)n, op, eps, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply_device: %s", hipGetErrorString(e));
+  return CVH_OK;
+}
+
+extern "C" int cvh_ppf_apply(double *data, int w, long start, long end, int op, double eps, int device)
+{
+  // data.at<double>(i / w, i % w) of a continuous w-wide matrix is data[i]
+  if (!data || w <= 0 || start < 0 || end < start || op < 0 || op > 2)
+    return fail(nullptr, CVH_ERR_ARG, "cvh_ppf_apply: bad argument");
+  if (end == start) return CVH_OK;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: hipSetDevice: %s (no CPU fallback)", hipGetErrorString(e));
+  const size_t n = (size_t)(end - start);
+  double *d = nullptr;
+  if ((e = hipMalloc((void **)&d, n * sizeof(double))) != hipSuccess)
+    return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: hipMalloc: %s", hipGetErrorString(e));
+  do {
+    if ((e = hipMemcpy(d, data + start, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = cvh_launch_ppf(d, n, op, eps, nullptr)) != hipSuccess) break;
+    e = hipMemcpy(data + start, d, n * sizeof(double), hipMemcpyDeviceToHost);
+  } while (0);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: %s", hipGetErrorString(e));
+  return CVH_OK;
+}

@@ -1,0 +1,73 @@
+// cvh_internal.h — shared declarations of the HIP implementation behind include/chanvese_hip.h.
+// gfx950 (CDNA4, wave64) only.  Citations are file:line in the reference repository.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chanvese_hip.h"
+
+#define CVH_BLOCK 256  // 4 waves of 64
+
+// Device-resident scalar state of one context.  Written only by the finalising workgroup
+// of a kernel and read by the next kernel on the same stream (kernel boundary = visibility).
+struct CvhState {
+  double c1[CVH_MAX_CHANNELS];  // region means of the current u, used by the next step (:973)
+  double c2[CVH_MAX_CHANNELS];  // (:974)
+  double norm;                  // ||u_diff||_2 of the last executed step (:993)
+  double stop_cond;             // tol * ||mean_k I_k||_2 (:959)
+  int steps_done;               // iterations executed since cvh_reset_run
+  int stopped;                  // sticky: stop rule fired (:1000); later launches are no-ops
+  unsigned ticket;              // arrival counter of the in-kernel finalisation
+  int pad;
+};
+
+// Sums carried per workgroup and reduced in a fixed order (deterministic):
+//   [0] sum H(u)  [1] sum (1-H(u))  [2..2+C) sum I_k H  [2+C..2+2C) sum I_k (1-H)  [2+2C] sum u_diff^2
+__host__ __device__ constexpr int cvh_nsums(int C) { return 3 + 2 * C; }
+
+struct CvhStepArgs {
+  const double *u_in;
+  double *u_out;
+  const uint8_t *img[CVH_MAX_CHANNELS];
+  CvhState *st;
+  double *partials;  // [nblocks][nsums]
+  double *trace;     // [trace_cap][2C+1] or null
+  int trace_cap;
+  int h, w;
+  int tiles_x, tiles_y;
+  int nparts;        // number of partial rows the finaliser must add
+  int fused_finalize;
+  double alpha, beta, gamma;  // dt*mu, dt*(1/C), -nu*dt : addWeighted form of :985
+  double eps;
+  double lambda1[CVH_MAX_CHANNELS], lambda2[CVH_MAX_CHANNELS];
+};
+
+struct CvhPmArgs {
+  const double *in;
+  double *out;
+  int h, w;
+  int tiles_x, tiles_y;
+  double K2;  // K*K (:520)
+  double L;
+};
+
+// ---- launchers (csv_kernels.hip / pm_kernels.hip / misc_kernels.hip) ----
+// rows-per-tile options of the step kernel
+int cvh_step_tile_rows(int h, int w);
+void cvh_step_grid(int h, int w, int *tiles_x, int *tiles_y);
+hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
+hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,
+                                hipStream_t s);
+hipError_t cvh_launch_finalize(const CvhStepArgs &a, int channels, int is_init, hipStream_t s);
+int cvh_init_sum_blocks(int h, int w);
+
+hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hipStream_t s);
+hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s);
+hipError_t cvh_launch_pm_store(const double *state, uint8_t *plane, size_t n, hipStream_t s);
+void cvh_pm_grid(int h, int w, int *tiles_x, int *tiles_y);
+
+hipError_t cvh_launch_mask(const double *u, uint8_t *mask, size_t n, int invert, hipStream_t s);
+hipError_t cvh_launch_ppf(double *data, size_t n, int op, double eps, hipStream_t s);
+hipError_t cvh_launch_separate(const uint8_t *img3, const double *u, uint8_t *sel3, size_t n,
+                               int invert, hipStream_t s);

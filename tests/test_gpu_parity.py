@@ -1,0 +1,253 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(chan_vese_amd.capi -> libchanvese_hip.so), against the CPU oracle on the same seeded inputs.
+
+Stated tolerances (FP64 state): per-pixel max|u_gpu - u_cpu| / max|u_cpu|
+  <= 1e-9 over the first ten iterations, <= 1e-6 after the configured iteration count;
+  c1/c2 relative <= 1e-9 per iteration; mask IoU >= 0.999; identical stop iteration.
+The only sources of difference are the device atan, the summation order of the region sums
+and (FAST mode) <= 2 ulp rsqrt/rcp refinements."""
+import numpy as np
+import pytest
+
+from chan_vese_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+MODES = [("strict", 1), ("fast", 2)]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from chan_vese_amd import capi as m
+    m.lib()
+    assert m.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return m
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def iou(a, b):
+    a, b = a.astype(bool), b.astype(bool)
+    u = (a | b).sum()
+    return 1.0 if u == 0 else (a & b).sum() / u
+
+
+def gpu_run(capi, planes, u0, steps, math=1, finalize=0, trace=True, **pk):
+    h, w = planes[0].shape
+    with capi.Context(h, w, len(planes), capi.make_params(**pk)) as ctx:
+        ctx.set_option("math_mode", math)
+        ctx.set_option("finalize", finalize)
+        if trace:
+            ctx.set_option("trace", max(steps, 1))
+        ctx.set_image(planes)
+        ctx.set_levelset(u0)
+        done, nrm = ctx.run(steps)
+        return ctx.get_levelset(), done, nrm, ctx.get_trace(steps) if trace else None, ctx.get_mask()
+
+
+@pytest.mark.parametrize("mode,math", MODES)
+@pytest.mark.parametrize("finalize", [0, 1])
+@pytest.mark.parametrize("shape", [(32, 48), (64, 64), (37, 53), (1, 40), (40, 1), (2, 2), (3, 700),
+                                   (100, 517)])
+def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize):
+    h, w = shape
+    rng = np.random.default_rng(h * 7919 + w)
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    u0 = oracle.checkerboard(h, w) if min(h, w) > 2 else rng.normal(size=shape)
+    for steps in (1, 2, 3, 10):
+        u_c, done_c, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(tol=0), steps)
+        u_g, done_g, nrm_g, tr_g, _ = gpu_run(capi, [img], u0, steps, math, finalize, tol=0)
+        assert done_g == done_c == steps
+        assert rel_err(u_g, u_c) <= 1e-9, (steps, rel_err(u_g, u_c))
+        assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0), (tr_g, tr_c)
+        assert nrm_g == pytest.approx(nrm_c, rel=1e-9)
+
+
+@pytest.mark.parametrize("mode,math", MODES)
+def test_csv_nondefault_params(capi, oracle, mode, math):
+    h, w = 48, 300
+    img = synth.disk(48, 180, 70, noise=20, seed=5, h=h, w=w)
+    u0 = oracle.checkerboard(h, w)
+    pk = dict(mu=0.2, nu=0.05, dt=0.1, eps=0.5, tol=0)
+    u_c, _, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(**pk), 10)
+    u_g, _, nrm_g, tr_g, _ = gpu_run(capi, [img], u0, 10, math, **pk)
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("mode,math", MODES)
+def test_csv_three_channel(capi, oracle, mode, math):
+    h, w = 80, 272
+    planes = [synth.disk(80, 180, 40, h=h, w=w), synth.disk(80, 200, 60, h=h, w=w),
+              synth.disk(80, 60, 200, h=h, w=w)]
+    pk = dict(tol=0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1])
+    u0 = oracle.checkerboard(h, w)
+    u_c, _, _, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), 10)
+    u_g, _, _, tr_g, m_g = gpu_run(capi, planes, u0, 10, math, **pk)
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+    assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+@pytest.mark.parametrize("mode,math", MODES)
+def test_config1_512_disk_100_iters(capi, oracle, mode, math):
+    """BASELINE.json configs[0]: 512x512 disk, checkerboard init, 100 CSV iterations."""
+    img = synth.disk(512)
+    u0 = oracle.checkerboard(512, 512)
+    u_c, done_c, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(tol=0), 100)
+    u_g, done_g, nrm_g, tr_g, m_g = gpu_run(capi, [img], u0, 100, math, tol=0)
+    assert done_g == done_c == 100
+    assert np.allclose(tr_g[:10], tr_c[:10], rtol=1e-9, atol=0)
+    assert rel_err(u_g, u_c) <= 1e-6, rel_err(u_g, u_c)
+    assert iou(m_g, oracle.mask(u_c)) >= 0.999
+    assert iou(m_g, img == 200) == 1.0
+
+
+def test_checkerboard_host_matches_oracle(capi, oracle):
+    assert np.array_equal(capi.checkerboard_host(301, 517), oracle.checkerboard(301, 517))
+    with capi.Context(64, 80, 1) as ctx:
+        ctx.init_checkerboard()
+        assert np.array_equal(ctx.get_levelset(), oracle.checkerboard(64, 80))
+
+
+def test_stop_rule_same_iteration(capi, oracle):
+    """Default tolerance: the loop must break at the reference's iteration (after the update)."""
+    img = synth.disk(128, 200, 50)
+    u0 = oracle.checkerboard(128, 128)
+    for tol in (1e-3, 0.05, 0.5):
+        u_c, done_c, nrm_c, _ = oracle.csv_run([img], u0, oracle.make_params(tol=tol), 400)
+        for sync_every in (1, 7, 32):
+            with capi.Context(128, 128, 1, capi.make_params(tol=tol)) as ctx:
+                ctx.set_option("sync_every", sync_every)
+                ctx.set_image([img])
+                ctx.set_levelset(u0)
+                assert ctx.get_stop_condition() == pytest.approx(oracle.stop_condition([img], tol), rel=1e-14)
+                done_g, nrm_g = ctx.run(400)
+                u_g = ctx.get_levelset()
+            assert done_g == done_c, (tol, sync_every, done_g, done_c)
+            assert nrm_g == pytest.approx(nrm_c, rel=1e-7)
+            assert rel_err(u_g, u_c) <= 1e-6
+
+
+def test_unlimited_steps_runs_to_stop(capi, oracle):
+    img = synth.disk(96, 220, 30)
+    u0 = oracle.checkerboard(96, 96)
+    u_c, done_c, _, _ = oracle.csv_run([img], u0, oracle.make_params(tol=0.2), 100000)
+    with capi.Context(96, 96, 1, capi.make_params(tol=0.2)) as ctx:
+        ctx.set_image([img])
+        ctx.set_levelset(u0)
+        done_g, _ = ctx.run(-1)      # src/main.cpp:890: negative => unlimited
+    assert done_g == done_c and done_c < 100000
+
+
+def test_run_continues_and_is_deterministic(capi, oracle):
+    img = synth.disk(200, 200, 50, noise=10, seed=2, h=120, w=530)
+    u0 = oracle.checkerboard(120, 530)
+    outs = []
+    for _ in range(2):
+        with capi.Context(120, 530, 1, capi.make_params(tol=0)) as ctx:
+            ctx.set_image([img])
+            ctx.set_levelset(u0)
+            ctx.run(7)
+            ctx.run(6)              # continue from the current level set
+            outs.append(ctx.get_levelset())
+    assert np.array_equal(outs[0], outs[1])       # fixed summation order => bitwise reproducible
+    u_c, _, _, _ = oracle.csv_run([img], u0, oracle.make_params(tol=0), 13)
+    assert rel_err(outs[0], u_c) <= 1e-9
+
+
+def test_enqueue_sync_interleaved_contexts(capi, oracle):
+    """Two independent images on one GPU driven through the asynchronous halves of cvh_run."""
+    imgs = [synth.disk(96, 200, 50, noise=5, seed=s) for s in (1, 2)]
+    u0 = oracle.checkerboard(96, 96)
+    ctxs = [capi.Context(96, 96, 1, capi.make_params(tol=0)) for _ in imgs]
+    for c, im in zip(ctxs, imgs):
+        c.set_image([im])
+        c.set_levelset(u0)
+    for _ in range(3):
+        for c in ctxs:
+            c.enqueue_steps(4)
+    for c, im in zip(ctxs, imgs):
+        done, nrm, stopped = c.sync()
+        assert done == 12 and not stopped
+        u_c, _, _, _ = oracle.csv_run([im], u0, oracle.make_params(tol=0), 12)
+        assert rel_err(c.get_levelset(), u_c) <= 1e-9
+        c.close()
+
+
+@pytest.mark.parametrize("shape,K,L,T", [((40, 56), 30, 0.25, 5), ((64, 64), 10, 0.25, 20),
+                                         ((37, 130), 1000, 0.1, 1.5), ((1, 50), 30, 0.25, 2),
+                                         ((50, 1), 30, 0.25, 2), ((3, 3), 30, 0.2, 1)])
+def test_perona_malik_parity(capi, oracle, shape, K, L, T):
+    h, w = shape
+    rng = np.random.default_rng(11 + h + w)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]
+    cpu = oracle.perona_malik(planes, K, L, T)
+    with capi.Context(h, w, 3) as ctx:
+        ctx.set_image(planes)
+        ctx.perona_malik(K, L, T)
+        gpu = ctx.get_image()
+    assert capi.pm_trip_count(L, T) == oracle.pm_trip_count(L, T)
+    for g, c in zip(gpu, cpu):
+        assert (g != c).sum() == 0       # bit-exact uint8 (contraction off on both sides)
+
+
+def test_pm_then_csv_pipeline(capi, oracle):
+    """Config 4 in miniature: PM-smoothed 8-bit image feeds CSV and the stop condition."""
+    img = synth.disk(96, 200, 50, noise=32, seed=1)
+    u0 = oracle.checkerboard(96, 96)
+    sm = oracle.perona_malik([img], 30, 0.25, 10)
+    u_c, done_c, _, _ = oracle.csv_run(sm, u0, oracle.make_params(tol=1e-3), 60)
+    with capi.Context(96, 96, 1, capi.make_params(tol=1e-3)) as ctx:
+        ctx.set_image([img])
+        ctx.perona_malik(30, 0.25, 10)
+        ctx.set_levelset(u0)
+        assert ctx.get_stop_condition() == pytest.approx(oracle.stop_condition(sm, 1e-3), rel=1e-14)
+        done_g, _ = ctx.run(60)
+        u_g = ctx.get_levelset()
+    assert done_g == done_c
+    assert rel_err(u_g, u_c) <= 1e-6
+
+
+def test_mask_and_separate(capi, oracle):
+    rng = np.random.default_rng(4)
+    u = rng.normal(size=(33, 47))
+    u[0, :5] = [1e-50, -1e-50, 0.0, 1e-46, 5e-324]
+    img3 = rng.integers(0, 256, size=(33, 47, 3), dtype=np.uint8)
+    with capi.Context(33, 47, 1) as ctx:
+        ctx.set_levelset(u)
+        for inv in (False, True):
+            assert np.array_equal(ctx.get_mask(inv), oracle.mask(u, inv))
+            assert np.array_equal(ctx.separate(img3, inv), oracle.separate(img3, u, inv))
+
+
+@pytest.mark.parametrize("op", [0, 1, 2])
+def test_parallel_pixel_function_ops(capi, oracle, op):
+    """ParallelPixelFunction(data, w, f)(Range(a, b)) — src/ParallelPixelFunction.cpp:12-17."""
+    rng = np.random.default_rng(op)
+    data = rng.normal(scale=50, size=(19, 23))
+    for (a, b) in [(0, data.size), (5, 100), (7, 7), (436, 437)]:
+        g, c = data.copy(), data.copy()
+        capi.ppf_apply(g, op, eps=0.8, start=a, end=b)
+        oracle.ppf_apply(c, op, eps=0.8, start=a, end=b)
+        assert np.allclose(g, c, rtol=4e-16, atol=1e-300)
+        assert np.array_equal(g.ravel()[:a], data.ravel()[:a]) and np.array_equal(g.ravel()[b:], data.ravel()[b:])
+
+
+def test_error_paths(capi):
+    with pytest.raises(capi.CvhError):
+        capi.Context(0, 5)
+    with pytest.raises(capi.CvhError):
+        capi.Context(8, 8, channels=2)
+    with pytest.raises(capi.CvhError):
+        capi.Context(8, 8, params=capi.make_params(dt=0.0))
+    with capi.Context(8, 8) as ctx:
+        with pytest.raises(capi.CvhError):
+            ctx.run(1)                              # no image / level set yet
+        ctx.set_image([np.zeros((8, 8), np.uint8)])
+        with pytest.raises(capi.CvhError):
+            ctx.perona_malik(10, 0.3, 20)           # L > 0.25, src/main.cpp:863
+        with pytest.raises(capi.CvhError):
+            ctx.set_option("nonsense", 1)
