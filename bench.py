@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--math", default="default", choices=["default", "strict", "fast"])
     ap.add_argument("--finalize", type=int, default=0, choices=[0, 1])
+    ap.add_argument("--opt", action="append", default=[], help="context option key=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     return ap.parse_args()
@@ -79,6 +80,9 @@ def main():
         ctx = capi.Context(n, n, C, p, device=device)
         ctx.set_option("math_mode", math_mode)
         ctx.set_option("finalize", args.finalize)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
         ctx.set_image(planes)
         ctx.set_levelset(u0)
         ctxs.append(ctx)

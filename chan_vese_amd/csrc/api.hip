@@ -30,6 +30,12 @@ struct cvh_context {
   double stop_norm = 0.0;  // || (sum_k I_k)/C ||_2
   double stop_cond_h = 0.0; // staging for the async upload
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
+  int tile_rows = 16, use_lut = 1, use_dma = 0;
+  int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel
+  int strip_rows = 0;   // 0 auto
+  int num_cus = 256;
+  double *d_atan = nullptr;
+  double sum_img[CVH_MAX_CHANNELS] = {0, 0, 0};
   int tiles_x = 0, tiles_y = 0;
   int cur_base = 0;   // buffer that held u when the run counter was last reset
   int enqueued = 0;   // steps enqueued since then
@@ -62,7 +68,7 @@ static int fail(cvh_context *ctx, int code, const char *fmt, ...)
 
 static bool use_fast(const cvh_context *c)
 {
-  const int m = c->math_mode == CVH_MATH_DEFAULT ? CVH_MATH_STRICT : c->math_mode;
+  const int m = c->math_mode == CVH_MATH_DEFAULT ? CVH_MATH_FAST : c->math_mode;
   return m == CVH_MATH_FAST;
 }
 
@@ -111,6 +117,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->d_mask) (void)hipFree(c->d_mask);
+  if (c->d_atan) (void)hipFree(c->d_atan);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 2; ++k) if (c->evp[k]) (void)hipEventDestroy(c->evp[k]);
@@ -122,14 +129,29 @@ static int create_impl(cvh_context *c)
 {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->num_cus = cus;
+  }
   for (int k = 0; k < c->C; ++k) HIPCHK(c, hipMalloc((void **)&c->d_img[k], c->n));
   for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc((void **)&c->d_u[k], c->n * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_state, sizeof(CvhState)));
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_state, 2 * sizeof(CvhState), hipHostMallocDefault));
   memset(c->h_state, 0, 2 * sizeof(CvhState));
-  cvh_step_grid(c->h, c->w, &c->tiles_x, &c->tiles_y);
-  const int step_blocks = c->tiles_x * c->tiles_y;
+  cvh_step_grid(c->h, c->w, c->tile_rows, &c->tiles_x, &c->tiles_y);
+  const int step_blocks = cvh_step_max_blocks(c->h, c->w);
+  {
+    // atan(i/128) and pi/2 - atan(i/128), rounded once from long double
+    double tab[2 * CVH_ATAN_N];
+    for (int i = 0; i < CVH_ATAN_N; ++i) {
+      const long double at = atanl((long double)i / (CVH_ATAN_N - 1));
+      tab[i] = (double)at;
+      tab[CVH_ATAN_N + i] = (double)(1.57079632679489661923132169163975144L - at);
+    }
+    HIPCHK(c, hipMalloc((void **)&c->d_atan, sizeof(tab)));
+    HIPCHK(c, hipMemcpy(c->d_atan, tab, sizeof(tab), hipMemcpyHostToDevice));
+  }
   const int init_blocks = cvh_init_sum_blocks(c->h, c->w);
   c->partial_rows = step_blocks > init_blocks ? step_blocks : init_blocks;
   HIPCHK(c, hipMalloc((void **)&c->d_partials, (size_t)c->partial_rows * cvh_nsums(c->C) * sizeof(double)));
@@ -189,6 +211,20 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "finalize")) {
     if (value != 0 && value != 1) return fail(c, CVH_ERR_ARG, "finalize must be 0 or 1");
     c->finalize_mode = (int)value;
+  } else if (!strcmp(key, "tile_rows")) {
+    if (value != 12 && value != 14 && value != 16) return fail(c, CVH_ERR_ARG, "tile_rows must be 12, 14 or 16");
+    c->tile_rows = (int)value;
+  } else if (!strcmp(key, "kernel")) {
+    if (value < -1 || value > 1) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile) or 1 (strip)");
+    if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
+    c->kernel = (int)value;
+  } else if (!strcmp(key, "strip_rows")) {
+    if (value < 0) return fail(c, CVH_ERR_ARG, "strip_rows must be >= 0");
+    c->strip_rows = (int)value;
+  } else if (!strcmp(key, "lut")) {
+    c->use_lut = value != 0;
+  } else if (!strcmp(key, "dma")) {
+    c->use_dma = value != 0;
   } else if (!strcmp(key, "sync_every")) {
     if (value < 1) return fail(c, CVH_ERR_ARG, "sync_every must be >= 1");
     c->sync_every = (int)(value > 1000000 ? 1000000 : value);
@@ -211,9 +247,14 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
 
 // tol-free part of the stop condition, src/main.cpp:950-959 (zero-initialised accumulator,
 // channels added serially in k, scaled by 1/C, L2 norm with four squares per step).
-static double stop_norm_host(const std::vector<const uint8_t *> &planes, size_t n)
+static double stop_norm_host(const std::vector<const uint8_t *> &planes, size_t n, double *sums)
 {
   const int C = (int)planes.size();
+  for (int k = 0; k < C; ++k) {
+    unsigned long long t = 0;
+    for (size_t q = 0; q < n; ++q) t += planes[k][q];
+    sums[k] = (double)t;  // exact: < 2^53
+  }
   const double inv = 1.0 / C;
   double s = 0;
   size_t i = 0;
@@ -238,7 +279,7 @@ extern "C" int cvh_set_image(cvh_context *c, const uint8_t *const *planes)
   for (int k = 0; k < c->C; ++k)
     HIPCHK(c, hipMemcpyAsync(c->d_img[k], planes[k], c->n, hipMemcpyHostToDevice, c->stream));
   std::vector<const uint8_t *> pl(planes, planes + c->C);
-  c->stop_norm = stop_norm_host(pl, c->n);
+  c->stop_norm = stop_norm_host(pl, c->n, c->sum_img);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_image = true;
   c->stop_valid = true;
@@ -327,6 +368,36 @@ extern "C" int cvh_get_levelset(cvh_context *c, double *u)
   return CVH_OK;
 }
 
+struct Geometry { int strip; int rows; int tiles_x, tiles_y, strip_rows, nblocks; };
+
+// Which step kernel runs and on what grid.  The strip kernel (16-byte pieces) needs
+// w % 16 == 0; its grid is one balanced round of resident workgroups.
+static Geometry resolve_geometry(const cvh_context *c)
+{
+  Geometry g;
+  g.strip = c->kernel == 1 || (c->kernel == -1 && (c->w % 16) == 0);
+  if (g.strip) {
+    g.rows = c->tile_rows == 12 ? 12 : 16;
+    g.tiles_x = (c->w + 255) / 256;
+    int sr = c->strip_rows;
+    if (sr <= 0) {
+      const int per_cu = 4;  // measured best on MI355X at 4096^2 (profiles/README.md)
+      int nseg = (c->num_cus * per_cu) / g.tiles_x;
+      if (nseg < 1) nseg = 1;
+      sr = (c->h + nseg - 1) / nseg;
+    }
+    sr = ((sr + g.rows - 1) / g.rows) * g.rows;
+    g.strip_rows = sr;
+    g.tiles_y = (c->h + sr - 1) / sr;
+  } else {
+    g.rows = c->tile_rows == 16 ? 16 : 14;  // tile kernel: 14 rows keep 4 workgroups per CU with the LUT
+    cvh_step_grid(c->h, c->w, g.rows, &g.tiles_x, &g.tiles_y);
+    g.strip_rows = g.rows;
+  }
+  g.nblocks = g.tiles_x * g.tiles_y;
+  return g;
+}
+
 static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
 {
   memset(a, 0, sizeof(*a));
@@ -338,8 +409,11 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->trace = c->d_trace;
   a->trace_cap = c->trace_cap;
   a->h = c->h; a->w = c->w;
-  a->tiles_x = c->tiles_x; a->tiles_y = c->tiles_y;
-  a->nparts = c->tiles_x * c->tiles_y;
+  Geometry g = resolve_geometry(c);
+  a->tiles_x = g.tiles_x; a->tiles_y = g.tiles_y;
+  a->nparts = g.nblocks;
+  a->tile_rows = g.rows;
+  a->strip_rows = g.strip_rows;
   a->fused_finalize = c->finalize_mode == 0;
   // src/main.cpp:985: dt * (mu*kappa - nu + u_diff/N) evaluates as one addWeighted
   a->alpha = c->p.mu * c->p.dt;
@@ -347,6 +421,16 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->gamma = -c->p.nu * c->p.dt;
   a->eps = c->p.eps;
   for (int k = 0; k < CVH_MAX_CHANNELS; ++k) { a->lambda1[k] = c->p.lambda1[k]; a->lambda2[k] = c->p.lambda2[k]; }
+  const double pi = 3.14159265358979323846;
+  a->atan_tab = c->d_atan;
+  a->inv_eps = 1.0 / c->p.eps;
+  a->dk1 = pi / c->p.eps;
+  a->dk2 = pi * c->p.eps;
+  a->npix = (double)c->n;
+  for (int k = 0; k < CVH_MAX_CHANNELS; ++k) a->sum_img[k] = c->sum_img[k];
+  a->derive_complement = use_fast(c) ? 1 : 0;
+  a->use_lut = c->use_lut;
+  a->use_dma = c->use_dma;
 }
 
 // Makes c1/c2 of the current level set and the stop condition valid on the device.
@@ -363,7 +447,7 @@ static int prepare(cvh_context *c)
       pl.push_back(host[k].data());
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stop_norm = stop_norm_host(pl, c->n);
+    c->stop_norm = stop_norm_host(pl, c->n, c->sum_img);
     c->stop_valid = true;
   }
   c->stop_cond_h = c->p.tol * c->stop_norm;  // :959
@@ -385,7 +469,8 @@ static int enqueue_impl(cvh_context *c, int nsteps)
   for (int s = 0; s < nsteps; ++s) {
     CvhStepArgs a;
     fill_args(c, &a, (c->cur_base + c->enqueued) & 1);
-    HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
+    if (resolve_geometry(c).strip) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
+    else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
     if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
     c->enqueued++;
   }

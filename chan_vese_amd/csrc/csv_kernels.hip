@@ -20,172 +20,90 @@
 // Compile with -ffp-contract=off: the STRICT flavour then rounds every per-pixel operation
 // exactly as the reference's x86-64 -O3 build (no FMA); the FAST flavour asks for FMAs
 // explicitly.
-#include "cvh_internal.h"
+#include "csv_device.h"
+
+using namespace cvh_dev;
 
 namespace {
 
-constexpr double kPi = 3.14159265358979323846;  // boost::math::constants::pi<double>()
-constexpr double kEta2 = 1E-8 * 1E-8;           // std::pow(eta, 2), src/main.cpp:347-348
-constexpr int TW = 256;                          // tile width = one column per thread
-constexpr int PITCH = TW + 4;                    // LDS row pitch (halo 2 + 2)
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// 1/sqrt(s) to <= 1 ulp from the hardware estimate with one cubic (Halley) step.
-__device__ __forceinline__ double rsqrt_refined(double s)
+// ---- tile staging ---------------------------------------------------------------------
+// Asynchronous global -> LDS copy of the (ROWS x PITCH) tile in 16-byte pieces
+// (global_load_lds_dwordx4: no VGPR round trip, every piece of the tile in flight at once).
+// One wave-instruction writes 64 consecutive pieces = 1 KiB of the linear LDS image; the
+// SOURCE address is per lane (row/column of the piece, clamped into the image).  Needs an
+// even width (16-byte aligned rows).  Out-of-image columns are patched at read time.
+template <int ROWS>
+__device__ __forceinline__ void stage_tile_dma(const double *u_in, double *su, int i0, int j0, int h,
+                                               int w, int tid)
 {
-  const double r = __builtin_amdgcn_rsq(s);
-  const double e = __builtin_fma(-(s * r), r, 1.0);           // 1 - s r^2
-  const double p = __builtin_fma(e, 0.375, 0.5);              // 1/2 + 3e/8
-  return __builtin_fma(r * e, p, r);                          // r (1 + e/2 + 3e^2/8)
-}
-
-// 1/q the same way (cubic step on the hardware reciprocal).
-__device__ __forceinline__ double rcp_refined(double q)
-{
-  const double r = __builtin_amdgcn_rcp(q);
-  const double e = __builtin_fma(-q, r, 1.0);
-  return __builtin_fma(__builtin_fma(e, e, e), r, r);
-}
-
-// d+ / sqrt(d+^2 + d0^2 + eta^2): src/main.cpp:365-368 (same-axis pairing).
-template <bool FAST>
-__device__ __forceinline__ double normalised(double up, double uc)
-{
-  if (FAST) {
-    const double s = __builtin_fma(up, up, __builtin_fma(uc, uc, kEta2));
-    return up * rsqrt_refined(s);
-  }
-  return up / sqrt(up * up + uc * uc + kEta2);
-}
-
-// central difference as filter2D evaluates it: (-0.5)*a + 0.5*b (exactly 0.5*(b-a)).
-__device__ __forceinline__ double central(double a, double b) { return -0.5 * a + 0.5 * b; }
-
-// value of `v` in lane-1; lane 0 of the wave receives `edge`.
-__device__ __forceinline__ double from_left_lane(double v, double edge)
-{
-  const long long vb = __double_as_longlong(v), eb = __double_as_longlong(edge);
-  const int lo = __builtin_amdgcn_update_dpp((int)eb, (int)vb, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(eb >> 32), (int)(vb >> 32), 0x138, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-__device__ __forceinline__ double read_lane(double v, int l)
-{
-  const long long vb = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)vb, l);
-  const int hi = __builtin_amdgcn_readlane((int)(vb >> 32), l);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// H_eps and its complement for the sums (src/main.cpp:193, :267).
-template <bool FAST>
-__device__ __forceinline__ double heaviside(double x, double eps)
-{
-  (void)FAST;
-  return (1 + 2 / kPi * atan(x / eps)) / 2;
-}
-
-// Adds acc[] over the workgroup in a fixed order; on return threads tid < NS hold the
-// workgroup total of sum tid in `total` (others undefined).
-template <int NS>
-__device__ __forceinline__ double block_reduce(double (&acc)[NS], double *sred /*[4*NS]*/)
-{
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CPR = PITCH / 2;  // 16-byte pieces per tile row
+  constexpr int NPIECE = ROWS * CPR;
+  const int wave_base = tid & ~63;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    double v = acc[s];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) sred[wave * NS + s] = v;
-  }
-  __syncthreads();
-  double total = 0;
-  if (tid < NS) total = ((sred[tid] + sred[NS + tid]) + sred[2 * NS + tid]) + sred[3 * NS + tid];
-  __syncthreads();
-  return total;
-}
-
-// Adds the partial rows (fixed order), then publishes c1/c2, norm, trace row, stop flag.
-// Called by all 256 threads of ONE workgroup.
-template <int C>
-__device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double *sfin)
-{
-  constexpr int NS = cvh_nsums(C);
-  const int tid = threadIdx.x;
-  double acc[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) acc[s] = 0;
-  for (int b = tid; b < a.nparts; b += CVH_BLOCK) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-      acc[s] += __hip_atomic_load(&a.partials[(size_t)b * NS + s], __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const double total = block_reduce<NS>(acc, sred);
-  if (tid < NS) sfin[tid] = total;
-  __syncthreads();
-  if (tid == 0) {
-    CvhState *st = a.st;
-    if (!is_init) {
-      const double nrm = sqrt(sfin[2 + 2 * C]);
-      const int t = st->steps_done;  // index of the step just executed
-      if (a.trace && t < a.trace_cap) {
-        double *row = a.trace + (size_t)t * (2 * C + 1);
-        for (int k = 0; k < C; ++k) { row[k] = st->c1[k]; row[C + k] = st->c2[k]; }
-        row[2 * C] = nrm;
-      }
-      st->norm = nrm;
-      st->steps_done = t + 1;
-      if (nrm <= st->stop_cond) st->stopped = 1;  // src/main.cpp:1000, after the update
-    }
-    for (int k = 0; k < C; ++k) {
-      st->c1[k] = sfin[2 + k] / sfin[0];          // nom / denom, src/main.cpp:280
-      st->c2[k] = sfin[2 + C + k] / sfin[1];
-    }
-    st->ticket = 0;
-  }
-}
-
-template <int C>
-__device__ __forceinline__ void publish_partials_and_maybe_finalize(const CvhStepArgs &a,
-                                                                    double total, double *sred,
-                                                                    double *sfin, int *s_last,
-                                                                    int nblocks)
-{
-  constexpr int NS = cvh_nsums(C);
-  const int tid = threadIdx.x;
-  // write-through (sc1) stores of this workgroup's row, drained before the ticket
-  if (tid < NS)
-    __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NS + tid], total, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  if (!a.fused_finalize) return;
-  if (tid < 64) {  // the storing wave is the signalling wave
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(&a.st->ticket, 1u, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-      *s_last = (t == (unsigned)nblocks - 1u);
-      if (*s_last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+  for (int rd = 0; rd < (NPIECE + CVH_BLOCK - 1) / CVH_BLOCK; ++rd) {
+    const int k = rd * CVH_BLOCK + tid;
+    if (k < NPIECE) {
+      const int r = k / CPR, cc = k - r * CPR;
+      const int gi = clampi(i0 - 2 + r, 0, h - 1), gj = clampi(j0 - 2 + 2 * cc, 0, w - 2);
+      const double *g = u_in + ((size_t)gi * w + gj);
+      double *l = su + 2 * (rd * CVH_BLOCK + wave_base);  // wave-uniform base; HW adds lane*16
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)g,
+          (__attribute__((address_space(3))) void *)(unsigned int)(uintptr_t)l, 16, 0, 0);
     }
   }
-  __syncthreads();
-  if (*s_last) finalize<C>(a, 0, sred, sfin);
 }
 
-template <int C, int R, bool FAST>
+// Generic path (any width): all 8-byte loads issued before the first LDS write.
+template <int ROWS>
+__device__ __forceinline__ void stage_tile_regs(const double *u_in, double *su, int i0, int j0, int h,
+                                                int w, int tid)
+{
+  constexpr int N = ROWS * PITCH;
+  constexpr int NRD = (N + CVH_BLOCK - 1) / CVH_BLOCK;
+  double v[NRD];
+#pragma unroll
+  for (int rd = 0; rd < NRD; ++rd) {
+    const int idx = rd * CVH_BLOCK + tid;
+    const int q = idx < N ? idx : N - 1;
+    const int r = q / PITCH, c = q - r * PITCH;
+    const int gi = clampi(i0 - 2 + r, 0, h - 1), gj = clampi(j0 - 2 + c, 0, w - 1);
+    v[rd] = u_in[(size_t)gi * w + gj];
+  }
+#pragma unroll
+  for (int rd = 0; rd < NRD; ++rd) {
+    const int idx = rd * CVH_BLOCK + tid;
+    if (idx < N) su[idx] = v[rd];
+  }
+}
+
+// LDS layout of the step kernel (dynamic, one array, every carve offset a multiple of 16).
+template <int C, int R, bool FAST, bool LUT>
+struct StepSmem {
+  static constexpr int NS = cvh_nsums(C);
+  static constexpr int off_u = 0;                                        // (R+3) x PITCH doubles
+  static constexpr int off_red = off_u + (R + 3) * PITCH;                // 4*NS
+  static constexpr int off_fin = off_red + 4 * NS + (4 * NS) % 2;        // NS
+  static constexpr int off_atan = off_fin + NS + NS % 2;                 // FAST: 2*CVH_ATAN_N
+  static constexpr int off_lut = off_atan + (FAST ? 2 * CVH_ATAN_N : 0); // LUT: C*256
+  static constexpr int off_flag = off_lut + (LUT ? C * 256 : 0);         // 2 doubles (s_last)
+  static constexpr int doubles = off_flag + 2;
+  static constexpr size_t bytes = (size_t)doubles * sizeof(double);
+};
+
+template <int C, int R, bool FAST, bool LUT, bool DMA>
 __global__ __launch_bounds__(CVH_BLOCK) void csv_step_kernel(const CvhStepArgs a)
 {
+  using L = StepSmem<C, R, FAST, LUT>;
   constexpr int NS = cvh_nsums(C);
   constexpr int ROWS = R + 3;
-  __shared__ double su[ROWS * PITCH];
-  __shared__ double sred[4 * NS];
-  __shared__ double sfin[NS];
-  __shared__ int s_last;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *su = smem + L::off_u;
+  double *sred = smem + L::off_red;
+  double *sfin = smem + L::off_fin;
+  double *satan = smem + L::off_atan;
+  double *slut = smem + L::off_lut;
+  int *s_last = (int *)(smem + L::off_flag);
 
   if (a.st->stopped) return;  // sticky stop: src/main.cpp:1000
 
@@ -193,13 +111,22 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_step_kernel(const CvhStepArgs a
   const int h = a.h, w = a.w;
   const int bx = blockIdx.x % a.tiles_x, by = blockIdx.x / a.tiles_x;
   const int i0 = by * R, j0 = bx * TW;
-  if (tid == 0) s_last = 0;
+  if (tid == 0) *s_last = 0;
 
   // ---- stage the tile: rows i0-2 .. i0+R, columns j0-2 .. j0+TW+1, replicate by clamping
-  for (int idx = tid; idx < ROWS * PITCH; idx += CVH_BLOCK) {
-    const int r = idx / PITCH, c = idx - r * PITCH;
-    const int gi = clampi(i0 - 2 + r, 0, h - 1), gj = clampi(j0 - 2 + c, 0, w - 1);
-    su[idx] = a.u_in[(size_t)gi * w + gj];
+  if (DMA) stage_tile_dma<ROWS>(a.u_in, su, i0, j0, h, w, tid);
+  else stage_tile_regs<ROWS>(a.u_in, su, i0, j0, h, w, tid);
+
+  // ---- this thread's image samples for all R rows (addresses clamped, values of
+  // out-of-image pixels are never used)
+  const int gj = j0 + tid;
+  const int gjc = gj < w ? gj : w - 1;
+  unsigned char ib[C][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int gic = (i0 + r) < h ? (i0 + r) : h - 1;
+#pragma unroll
+    for (int k = 0; k < C; ++k) ib[k][r] = a.img[k][(size_t)gic * w + gjc];
   }
 
   double c1[C], c2[C], l1[C], l2[C];
@@ -207,6 +134,25 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_step_kernel(const CvhStepArgs a
   for (int k = 0; k < C; ++k) { c1[k] = a.st->c1[k]; c2[k] = a.st->c2[k]; l1[k] = a.lambda1[k]; l2[k] = a.lambda2[k]; }
   const double eps = a.eps;
   const double eps2 = eps * eps;
+
+  if (FAST) {
+    static_assert(2 * CVH_ATAN_N <= 2 * CVH_BLOCK, "atan table copy assumes two loads per thread");
+    const double t0 = a.atan_tab[tid];
+    const double t1 = a.atan_tab[tid + CVH_BLOCK < 2 * CVH_ATAN_N ? tid + CVH_BLOCK : 0];
+    satan[tid] = t0;
+    if (tid + CVH_BLOCK < 2 * CVH_ATAN_N) satan[tid + CVH_BLOCK] = t1;
+  }
+  if (LUT) {
+    // region term per 8-bit value: dt/C * (lambda2 (v-c2)^2 - lambda1 (v-c1)^2) [+ (-nu dt)]
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const double v = (double)tid;
+      const double d1 = v - c1[k], d2 = v - c2[k];
+      const double reg = (d2 * d2) * l2[k] - (d1 * d1) * l1[k];
+      slut[k * 256 + tid] = (k == 0) ? __builtin_fma(reg, a.beta, a.gamma) : reg * a.beta;
+    }
+  }
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---- normalised x-gradient of this wave's left-edge column, lanes <-> rows
@@ -218,7 +164,6 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_step_kernel(const CvhStepArgs a
   }
 
   const int c = tid + 2;
-  const int gj = j0 + tid;
   double um = su[1 * PITCH + c], u0 = su[2 * PITCH + c];
   double ny_prev = normalised<FAST>(u0 - um, central(su[c], u0));  // ny at row i0-1
 
@@ -230,8 +175,9 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_step_kernel(const CvhStepArgs a
   for (int r = 0; r < R; ++r) {
     const int gi = i0 + r;
     const double up = su[(r + 3) * PITCH + c];
-    const double uw = su[(r + 2) * PITCH + c - 1];
-    const double ue = su[(r + 2) * PITCH + c + 1];
+    // BORDER_REPLICATE in x at the image edge (the DMA path cannot clamp single columns)
+    const double uw = (gj == 0) ? u0 : su[(r + 2) * PITCH + c - 1];
+    const double ue = (gj >= w - 1) ? u0 : su[(r + 2) * PITCH + c + 1];
     const double nx = normalised<FAST>(ue - u0, central(uw, ue));  // :365-366
     const double ny = normalised<FAST>(up - u0, central(um, up));  // :367-368
     const double nxl = from_left_lane(nx, read_lane(nx_edge, r));
@@ -241,45 +187,71 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_step_kernel(const CvhStepArgs a
     const double kappa = kx + ky;  // :373
 
     const bool valid = (gi < h) && (gj < w);
-    const size_t g = (size_t)(valid ? gi : 0) * w + (valid ? gj : 0);
+    int Iv[C];
     double Ik[C];
-    double ud = 0.0;  // :965
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-      Ik[k] = (double)a.img[k][g];
-      const double d1 = Ik[k] - c1[k], d2 = Ik[k] - c2[k];
-      const double vin = (d1 * d1) * l1[k];   // variance_penalty, :307-310
-      const double vout = (d2 * d2) * l2[k];
-      ud += vout - vin;                        // :979
-    }
-    double delta;
+    for (int k = 0; k < C; ++k) { Iv[k] = ib[k][r]; Ik[k] = (double)Iv[k]; }
+
+    double ud, hv;
     if (FAST) {
-      ud = __builtin_fma(kappa, a.alpha, __builtin_fma(ud, a.beta, a.gamma));
-      delta = eps * rcp_refined(kPi * __builtin_fma(u0, u0, eps2));
+      double reg;
+      if (LUT) {
+        reg = slut[Iv[0]];
+#pragma unroll
+        for (int k = 1; k < C; ++k) reg += slut[k * 256 + Iv[k]];
+      } else {
+        reg = 0.0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const double d1 = Ik[k] - c1[k], d2 = Ik[k] - c2[k];
+          reg += (d2 * d2) * l2[k] - (d1 * d1) * l1[k];
+        }
+        reg = __builtin_fma(reg, a.beta, a.gamma);
+      }
+      ud = __builtin_fma(kappa, a.alpha, reg);                                   // :985
+      const double q = __builtin_fma(u0 * u0, a.dk1, a.dk2);                     // 1/delta_eps(u)
+      const double r0 = __builtin_amdgcn_rcp(q);
+      const double e = __builtin_fma(-q, r0, 1.0);
+      ud = ud * __builtin_fma(__builtin_fma(e, e, e), r0, r0);                   // :992
     } else {
-      ud = kappa * a.alpha + ud * a.beta + a.gamma;   // :985
-      delta = eps / (kPi * (eps2 + u0 * u0));          // :209
-    }
-    ud = ud * delta;                                   // :992
-    const double un = u0 + ud;                         // :994
-    const double hv = heaviside<FAST>(un, eps);
-    const double omh = 1 - hv;
-    if (valid) {
-      a.u_out[g] = un;
-      acc[0] += hv;
-      acc[1] += omh;
+      ud = 0.0;  // :965
 #pragma unroll
       for (int k = 0; k < C; ++k) {
-        acc[2 + k] += Ik[k] * hv;        // :276
-        acc[2 + C + k] += Ik[k] * omh;
+        const double d1 = Ik[k] - c1[k], d2 = Ik[k] - c2[k];
+        const double vin = (d1 * d1) * l1[k];   // variance_penalty, :307-310
+        const double vout = (d2 * d2) * l2[k];
+        ud += vout - vin;                        // :979
       }
-      acc[2 + 2 * C] += ud * ud;         // :993
+      ud = kappa * a.alpha + ud * a.beta + a.gamma;        // :985
+      ud = ud * (eps / (kPi * (eps2 + u0 * u0)));           // :209, :992
     }
+    const double un = u0 + ud;                              // :994
+    if (FAST)
+      hv = __builtin_fma(atan_table(un * a.inv_eps, satan), 1.0 / kPi, 0.5);
+    else
+      hv = heaviside_strict(un, eps);
+    if (valid) a.u_out[(size_t)gi * w + gj] = un;
+    // out-of-image lanes add exact zeros
+    const double hz = valid ? hv : 0.0;
+    const double udz = valid ? ud : 0.0;
+    acc[0] += hz;
+    if (!FAST) acc[1] += valid ? 1 - hv : 0.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if (FAST) {
+        acc[2 + k] = __builtin_fma(Ik[k], hz, acc[2 + k]);
+      } else {
+        acc[2 + k] += Ik[k] * hz;          // :276
+        acc[2 + C + k] += valid ? Ik[k] * (1 - hv) : 0.0;
+      }
+    }
+    if (FAST) acc[2 + 2 * C] = __builtin_fma(udz, udz, acc[2 + 2 * C]);
+    else acc[2 + 2 * C] += udz * udz;      // :993
     um = u0; u0 = up; ny_prev = ny;
   }
 
   const double total = block_reduce<NS>(acc, sred);
-  publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, &s_last, gridDim.x);
+  publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, s_last, gridDim.x);
 }
 
 // Sums of H(u), (1-H(u)), I H, I (1-H) for the initial level set (seeds c1/c2 of step 1).
@@ -293,7 +265,7 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_init_sums_kernel(const CvhStepA
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0;
   for (size_t q = (size_t)blockIdx.x * CVH_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * CVH_BLOCK) {
-    const double hv = heaviside<false>(a.u_in[q], a.eps);
+    const double hv = heaviside_strict(a.u_in[q], a.eps);
     const double omh = 1 - hv;
     acc[0] += hv;
     acc[1] += omh;
@@ -318,27 +290,42 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_finalize_kernel(const CvhStepAr
   finalize<C>(a, is_init, sred, sfin);
 }
 
-constexpr int kRows = 16;
+template <int C, int R, bool FAST, bool LUT>
+hipError_t launch_step_v(const CvhStepArgs &a, hipStream_t s)
+{
+  using L = StepSmem<C, R, FAST, LUT>;
+  static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
+  const dim3 grid(a.tiles_x * a.tiles_y), block(CVH_BLOCK);
+  // the LDS-DMA loader needs 16-byte aligned rows: even width (hipMalloc bases are aligned)
+  if (a.use_dma && (a.w % 2 == 0) && a.w >= 2)
+    hipLaunchKernelGGL((csv_step_kernel<C, R, FAST, LUT, true>), grid, block, L::bytes, s, a);
+  else
+    hipLaunchKernelGGL((csv_step_kernel<C, R, FAST, LUT, false>), grid, block, L::bytes, s, a);
+  return hipGetLastError();
+}
 
 template <int C>
 hipError_t launch_step_c(const CvhStepArgs &a, int fast, hipStream_t s)
 {
-  const dim3 grid(a.tiles_x * a.tiles_y), block(CVH_BLOCK);
-  if (fast)
-    hipLaunchKernelGGL((csv_step_kernel<C, kRows, true>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((csv_step_kernel<C, kRows, false>), grid, block, 0, s, a);
-  return hipGetLastError();
+  if (!fast) return a.tile_rows == 14 ? launch_step_v<C, 14, false, false>(a, s) : launch_step_v<C, 16, false, false>(a, s);
+  if (a.tile_rows == 14)
+    return a.use_lut ? launch_step_v<C, 14, true, true>(a, s) : launch_step_v<C, 14, true, false>(a, s);
+  return a.use_lut ? launch_step_v<C, 16, true, true>(a, s) : launch_step_v<C, 16, true, false>(a, s);
 }
 
 }  // namespace
 
-int cvh_step_tile_rows(int, int) { return kRows; }
-
-void cvh_step_grid(int h, int w, int *tiles_x, int *tiles_y)
+void cvh_step_grid(int h, int w, int tile_rows, int *tiles_x, int *tiles_y)
 {
   *tiles_x = (w + TW - 1) / TW;
-  *tiles_y = (h + kRows - 1) / kRows;
+  *tiles_y = (h + tile_rows - 1) / tile_rows;
+}
+
+int cvh_step_max_blocks(int h, int w)
+{
+  int tx, ty;
+  cvh_step_grid(h, w, 12, &tx, &ty);  // smallest rows-per-workgroup of any step kernel
+  return tx * ty;
 }
 
 hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s)

@@ -41,7 +41,20 @@ struct CvhStepArgs {
   double alpha, beta, gamma;  // dt*mu, dt*(1/C), -nu*dt : addWeighted form of :985
   double eps;
   double lambda1[CVH_MAX_CHANNELS], lambda2[CVH_MAX_CHANNELS];
+  // FAST flavour only
+  const double *atan_tab;        // [2][CVH_ATAN_N]: atan(i/(N-1)) and pi/2 - atan(i/(N-1))
+  double inv_eps;                // 1/eps
+  double dk1, dk2;               // pi/eps, pi*eps : delta_eps(u) = 1 / (dk1*u^2 + dk2)
+  double npix;                   // h*w
+  double sum_img[CVH_MAX_CHANNELS];  // exact integer sums of the planes (complements are derived)
+  int derive_complement;         // sums [1] and [2+C..] are N - sum H, sum I - sum I H
+  int tile_rows;                 // rows per tile of the step kernel
+  int use_lut;
+  int use_dma;                   // LDS-DMA tile loader (even widths)
+  int strip_rows;                // rows per workgroup of the strip kernel (multiple of tile_rows)
 };
+
+#define CVH_ATAN_N 129
 
 struct CvhPmArgs {
   const double *in;
@@ -54,9 +67,10 @@ struct CvhPmArgs {
 
 // ---- launchers (csv_kernels.hip / pm_kernels.hip / misc_kernels.hip) ----
 // rows-per-tile options of the step kernel
-int cvh_step_tile_rows(int h, int w);
-void cvh_step_grid(int h, int w, int *tiles_x, int *tiles_y);
+void cvh_step_grid(int h, int w, int tile_rows, int *tiles_x, int *tiles_y);
+int cvh_step_max_blocks(int h, int w);
 hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
+hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,
                                 hipStream_t s);
 hipError_t cvh_launch_finalize(const CvhStepArgs &a, int channels, int is_init, hipStream_t s);

@@ -34,11 +34,13 @@ def iou(a, b):
     return 1.0 if u == 0 else (a & b).sum() / u
 
 
-def gpu_run(capi, planes, u0, steps, math=1, finalize=0, trace=True, **pk):
+def gpu_run(capi, planes, u0, steps, math=1, finalize=0, trace=True, opts=None, **pk):
     h, w = planes[0].shape
     with capi.Context(h, w, len(planes), capi.make_params(**pk)) as ctx:
         ctx.set_option("math_mode", math)
         ctx.set_option("finalize", finalize)
+        for k, v in (opts or {}).items():
+            ctx.set_option(k, v)
         if trace:
             ctx.set_option("trace", max(steps, 1))
         ctx.set_image(planes)
@@ -63,6 +65,25 @@ def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize):
         assert rel_err(u_g, u_c) <= 1e-9, (steps, rel_err(u_g, u_c))
         assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0), (tr_g, tr_c)
         assert nrm_g == pytest.approx(nrm_c, rel=1e-9)
+
+
+@pytest.mark.parametrize("mode,math", MODES)
+@pytest.mark.parametrize("opts", [dict(kernel=0, tile_rows=14), dict(kernel=0, tile_rows=16, lut=0),
+                                  dict(kernel=0, tile_rows=14, dma=1),
+                                  dict(kernel=1, tile_rows=16, strip_rows=16),
+                                  dict(kernel=1, tile_rows=16, strip_rows=48),
+                                  dict(kernel=1, tile_rows=12, strip_rows=24, lut=0),
+                                  dict(kernel=1, tile_rows=12), dict(kernel=1, tile_rows=16)])
+def test_csv_kernel_variants(capi, oracle, mode, math, opts):
+    """Every data-flow variant of the step kernel (LDS tile / streaming strip, ring chunking,
+    ragged last chunk, LDS-DMA loader, LUT on/off) against the oracle on a multi-tile image."""
+    h, w = 150, 528
+    img = synth.disk(150, 190, 60, noise=12, seed=9, h=h, w=w)
+    u0 = oracle.checkerboard(h, w)
+    u_c, _, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(tol=0), 6)
+    u_g, _, nrm_g, tr_g, _ = gpu_run(capi, [img], u0, 6, math, opts=opts, tol=0)
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
 
 
 @pytest.mark.parametrize("mode,math", MODES)
