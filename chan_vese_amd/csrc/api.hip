@@ -30,7 +30,7 @@ struct cvh_context {
   double stop_norm = 0.0;  // || (sum_k I_k)/C ||_2
   double stop_cond_h = 0.0; // staging for the async upload
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
-  int tile_rows = 16, use_lut = 1, use_dma = 0;
+  int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
   int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
@@ -212,7 +212,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value != 0 && value != 1) return fail(c, CVH_ERR_ARG, "finalize must be 0 or 1");
     c->finalize_mode = (int)value;
   } else if (!strcmp(key, "tile_rows")) {
-    if (value != 12 && value != 14 && value != 16) return fail(c, CVH_ERR_ARG, "tile_rows must be 12, 14 or 16");
+    if (value != 0 && value != 12 && value != 14 && value != 16) return fail(c, CVH_ERR_ARG, "tile_rows must be 0 (auto), 12, 14 or 16");
     c->tile_rows = (int)value;
   } else if (!strcmp(key, "kernel")) {
     if (value < -1 || value > 1) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile) or 1 (strip)");
@@ -390,7 +390,7 @@ static Geometry resolve_geometry(const cvh_context *c)
     g.strip_rows = sr;
     g.tiles_y = (c->h + sr - 1) / sr;
   } else {
-    g.rows = c->tile_rows == 16 ? 16 : 14;  // tile kernel: 14 rows keep 4 workgroups per CU with the LUT
+    g.rows = c->tile_rows == 16 ? 16 : 14;  // auto = 14: keeps 4 workgroups per CU beside the tables
     cvh_step_grid(c->h, c->w, g.rows, &g.tiles_x, &g.tiles_y);
     g.strip_rows = g.rows;
   }
