@@ -46,23 +46,20 @@ def parse():
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    from chan_vese_amd import batch
+    # torch (if any) is imported inside init_distributed, BEFORE the HIP library is loaded, so
+    # that both share torch's bundled HIP runtime.  CHANVESE_DIST_BACKEND=gloo rehearses the
+    # multi-rank path on one GPU (all ranks on device 0).
+    dist, rank, world, local_rank = batch.init_distributed(os.environ.get("CHANVESE_DIST_BACKEND"))
     torch = None
-    if world > 1:
-        # torch first: its bundled HIP runtime must be the one this process shares
+    if dist is not None and dist.get_backend() == "nccl":
         import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
     from chan_vese_amd import capi, synth
 
     n, C = args.size, args.channels
-    device = local_rank if world > 1 else 0
+    device = local_rank % max(capi.device_count(), 1)
     math_mode = {"default": 0, "strict": 1, "fast": 2}[args.math]
 
     # ---- resident inputs: image b of this rank, checkerboard level set
@@ -104,8 +101,7 @@ def main():
         return out
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        batch.barrier(dist)
 
     run_steps(args.warmup)
     sync_all()
@@ -120,14 +116,11 @@ def main():
     kernel_ms = [ctx.last_run_ms() for ctx in ctxs]  # HIP events on each image's stream
     assert all(r[0] == args.warmup + args.steps and not r[2] for r in res), res
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    # end-of-run gather of the per-rank records (the only collective besides barriers/max)
+    records = batch.gather_records(dist, [args.images_per_gpu, float(n) * n * args.steps * args.images_per_gpu, elapsed])
+    elapsed = batch.max_over_ranks(dist, elapsed)
     total_images = world * args.images_per_gpu
-    px_iters = float(n) * n * args.steps * total_images
-    value = px_iters / elapsed / 1e6
+    value = batch.aggregate_throughput(records, elapsed)
 
     out = None
     if rank == 0:
@@ -159,7 +152,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "images_per_gpu": args.images_per_gpu,
-                       "state": "fp64", "math": args.math, "parallelism": f"batch-shard x{world}"},
+                       "state": "fp64", "math": args.math, "parallelism": f"batch-shard x{world}",
+                       "per_rank_mpx_it_s": [r[1] / r[2] / 1e6 for r in records]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "csv_step_kernel", "avg_launch_us": avg_launch_s * 1e6,

@@ -1,0 +1,67 @@
+"""N>1 path on CPU: world_size-2 gloo run of the batch-sharding / timing-aggregation logic
+bench.py uses (no GPU work here — the per-image compute is covered by the -m gpu tests)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from chan_vese_amd import batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_images_partitions_exactly():
+    for B, R in [(64, 8), (64, 1), (7, 2), (5, 8), (0, 3)]:
+        parts = [batch.shard_images(B, r, R) for r in range(R)]
+        flat = [b for p in parts for b in p]
+        assert flat == list(range(B))
+    assert batch.shard_images(64, 3, 8) == list(range(24, 32))      # C5: images 8r .. 8r+7 on GPU r
+    with pytest.raises(ValueError):
+        batch.shard_images(4, 2, 2)
+
+
+def test_aggregate_throughput():
+    recs = [[8, 8 * 500 * 4096.0 * 4096, 1.0], [8, 8 * 500 * 4096.0 * 4096, 1.25]]
+    assert batch.aggregate_throughput(recs, 1.25) == pytest.approx(16 * 500 * 4096 * 4096 / 1.25 / 1e6)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_gloo_gather_and_max(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        from chan_vese_amd import batch
+        dist, rank, world, local = batch.init_distributed(backend="gloo")
+        mine = batch.shard_images(64, rank, world)
+        batch.barrier(dist)
+        elapsed = 1.0 + 0.5 * rank
+        recs = batch.gather_records(dist, [len(mine), len(mine) * 1000.0, elapsed])
+        emax = batch.max_over_ranks(dist, elapsed)
+        batch.barrier(dist)
+        if rank == 0:
+            print(json.dumps(dict(world=world, mine=mine[:2], recs=recs, emax=emax,
+                                  value=batch.aggregate_throughput(recs, emax))))
+        dist.destroy_process_group()
+    """))
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world"] == 2 and d["mine"] == [0, 1]
+    assert d["recs"] == [[32.0, 32000.0, 1.0], [32.0, 32000.0, 1.5]]
+    assert d["emax"] == 1.5
+    assert d["value"] == pytest.approx(64000.0 / 1.5 / 1e6)
