@@ -139,7 +139,6 @@ static int create_impl(cvh_context *c)
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_state, 2 * sizeof(CvhState), hipHostMallocDefault));
   memset(c->h_state, 0, 2 * sizeof(CvhState));
-  cvh_step_grid(c->h, c->w, c->tile_rows, &c->tiles_x, &c->tiles_y);
   const int step_blocks = cvh_step_max_blocks(c->h, c->w);
   {
     // atan(i/128) and pi/2 - atan(i/128), rounded once from long double
