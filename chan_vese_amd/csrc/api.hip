@@ -31,7 +31,8 @@ struct cvh_context {
   double stop_cond_h = 0.0; // staging for the async upload
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
-  int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel
+  int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
+  int wave_minw = 6;
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
   double *d_atan = nullptr;
@@ -139,15 +140,22 @@ static int create_impl(cvh_context *c)
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_state, 2 * sizeof(CvhState), hipHostMallocDefault));
   memset(c->h_state, 0, 2 * sizeof(CvhState));
-  const int step_blocks = cvh_step_max_blocks(c->h, c->w);
+  int step_blocks = cvh_step_max_blocks(c->h, c->w);
+  {
+    const int wave_blocks = (((c->w + cvh_wave_cols() - 1) / cvh_wave_cols()) * c->h + 3) / 4 + 1;  // strip_rows >= 1
+    if (wave_blocks > step_blocks) step_blocks = wave_blocks;
+  }
   {
     // atan(i/128) and pi/2 - atan(i/128), rounded once from long double
-    double tab[2 * CVH_ATAN_N];
+    double tab[2 * CVH_ATAN_N + CVH_ATAN2_N];
+    const long double pil = 3.14159265358979323846264338327950288L;
     for (int i = 0; i < CVH_ATAN_N; ++i) {
       const long double at = atanl((long double)i / (CVH_ATAN_N - 1));
       tab[i] = (double)at;
-      tab[CVH_ATAN_N + i] = (double)(1.57079632679489661923132169163975144L - at);
+      tab[CVH_ATAN_N + i] = (double)(pil / 2 - at);
     }
+    for (int j = 0; j < CVH_ATAN2_N; ++j)  // (pi/4 + atan((j-128)/128)) / pi
+      tab[2 * CVH_ATAN_N + j] = (double)((pil / 4 + atanl((long double)(j - 128) / 128)) / pil);
     HIPCHK(c, hipMalloc((void **)&c->d_atan, sizeof(tab)));
     HIPCHK(c, hipMemcpy(c->d_atan, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
@@ -214,9 +222,12 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value != 0 && value != 12 && value != 14 && value != 16) return fail(c, CVH_ERR_ARG, "tile_rows must be 0 (auto), 12, 14 or 16");
     c->tile_rows = (int)value;
   } else if (!strcmp(key, "kernel")) {
-    if (value < -1 || value > 1) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile) or 1 (strip)");
+    if (value < -1 || value > 2) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile), 1 (strip) or 2 (wave)");
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
+  } else if (!strcmp(key, "wave_occupancy")) {
+    if (value < 5 || value > 8) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 5..8");
+    c->wave_minw = (int)value;
   } else if (!strcmp(key, "strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "strip_rows must be >= 0");
     c->strip_rows = (int)value;
@@ -375,6 +386,24 @@ static Geometry resolve_geometry(const cvh_context *c)
 {
   Geometry g;
   g.strip = c->kernel == 1 || (c->kernel == -1 && (c->w % 16) == 0);
+  if (c->kernel == 2) {
+    // wave kernel: 63 output columns per wave, strip_rows rows per wave, 4 waves per workgroup;
+    // one round of resident waves (wave_minw per SIMD)
+    g.strip = 2;
+    g.rows = 4;
+    g.tiles_x = (c->w + cvh_wave_cols() - 1) / cvh_wave_cols();
+    int sr = c->strip_rows;
+    if (sr <= 0) {
+      int nstrips = (c->num_cus * 4 * c->wave_minw) / g.tiles_x;
+      if (nstrips < 1) nstrips = 1;
+      sr = (c->h + nstrips - 1) / nstrips;
+      if (sr < 8) sr = 8;  // shorter strips only pay prologue overhead
+    }
+    g.strip_rows = sr;
+    g.tiles_y = (c->h + sr - 1) / sr;
+    g.nblocks = (g.tiles_x * g.tiles_y + 3) / 4;
+    return g;
+  }
   if (g.strip) {
     g.rows = c->tile_rows == 12 ? 12 : 16;
     g.tiles_x = (c->w + 255) / 256;
@@ -422,6 +451,8 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   for (int k = 0; k < CVH_MAX_CHANNELS; ++k) { a->lambda1[k] = c->p.lambda1[k]; a->lambda2[k] = c->p.lambda2[k]; }
   const double pi = 3.14159265358979323846;
   a->atan_tab = c->d_atan;
+  a->atan2_tab = c->d_atan + 2 * CVH_ATAN_N;
+  a->wave_minw = c->wave_minw;
   a->inv_eps = 1.0 / c->p.eps;
   a->dk1 = pi / c->p.eps;
   a->dk2 = pi * c->p.eps;
@@ -468,7 +499,9 @@ static int enqueue_impl(cvh_context *c, int nsteps)
   for (int s = 0; s < nsteps; ++s) {
     CvhStepArgs a;
     fill_args(c, &a, (c->cur_base + c->enqueued) & 1);
-    if (resolve_geometry(c).strip) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
+    const int kind = resolve_geometry(c).strip;
+    if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
+    else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
     else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
     if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
     c->enqueued++;

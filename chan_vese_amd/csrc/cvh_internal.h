@@ -51,10 +51,13 @@ struct CvhStepArgs {
   int tile_rows;                 // rows per tile of the step kernel
   int use_lut;
   int use_dma;                   // LDS-DMA tile loader (even widths)
-  int strip_rows;                // rows per workgroup of the strip kernel (multiple of tile_rows)
+  int strip_rows;                // rows per workgroup (strip kernel) / per wave (wave kernel)
+  const double *atan2_tab;       // [CVH_ATAN2_N]: (pi/4 + atan((j-128)/128)) / pi
+  int wave_minw;                 // waves per SIMD the wave kernel is compiled for (5..8)
 };
 
 #define CVH_ATAN_N 129
+#define CVH_ATAN2_N 257
 
 struct CvhPmArgs {
   const double *in;
@@ -71,6 +74,8 @@ void cvh_step_grid(int h, int w, int tile_rows, int *tiles_x, int *tiles_y);
 int cvh_step_max_blocks(int h, int w);
 hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
+hipError_t cvh_launch_wave(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
+int cvh_wave_cols();
 hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,
                                 hipStream_t s);
 hipError_t cvh_launch_finalize(const CvhStepArgs &a, int channels, int is_init, hipStream_t s);

@@ -50,17 +50,17 @@ def gpu_run(capi, planes, u0, steps, math=1, finalize=0, trace=True, opts=None, 
 
 
 @pytest.mark.parametrize("mode,math", MODES)
-@pytest.mark.parametrize("finalize", [0, 1])
+@pytest.mark.parametrize("finalize,kernel", [(0, -1), (1, -1), (0, 2)])
 @pytest.mark.parametrize("shape", [(32, 48), (64, 64), (37, 53), (1, 40), (40, 1), (2, 2), (3, 700),
                                    (100, 517)])
-def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize):
+def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize, kernel):
     h, w = shape
     rng = np.random.default_rng(h * 7919 + w)
     img = rng.integers(0, 256, size=shape, dtype=np.uint8)
     u0 = oracle.checkerboard(h, w) if min(h, w) > 2 else rng.normal(size=shape)
     for steps in (1, 2, 3, 10):
         u_c, done_c, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(tol=0), steps)
-        u_g, done_g, nrm_g, tr_g, _ = gpu_run(capi, [img], u0, steps, math, finalize, tol=0)
+        u_g, done_g, nrm_g, tr_g, _ = gpu_run(capi, [img], u0, steps, math, finalize, opts=dict(kernel=kernel), tol=0)
         assert done_g == done_c == steps
         assert rel_err(u_g, u_c) <= 1e-9, (steps, rel_err(u_g, u_c))
         assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0), (tr_g, tr_c)
@@ -73,7 +73,10 @@ def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize):
                                   dict(kernel=1, tile_rows=16, strip_rows=16),
                                   dict(kernel=1, tile_rows=16, strip_rows=48),
                                   dict(kernel=1, tile_rows=12, strip_rows=24, lut=0),
-                                  dict(kernel=1, tile_rows=12), dict(kernel=1, tile_rows=16)])
+                                  dict(kernel=1, tile_rows=12), dict(kernel=1, tile_rows=16),
+                                  dict(kernel=2), dict(kernel=2, strip_rows=8, lut=0),
+                                  dict(kernel=2, strip_rows=52, wave_occupancy=6),
+                                  dict(kernel=2, strip_rows=1000, wave_occupancy=7)])
 def test_csv_kernel_variants(capi, oracle, mode, math, opts):
     """Every data-flow variant of the step kernel (LDS tile / streaming strip, ring chunking,
     ragged last chunk, LDS-DMA loader, LUT on/off) against the oracle on a multi-tile image."""
