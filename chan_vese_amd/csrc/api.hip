@@ -19,7 +19,7 @@ struct cvh_context {
   uint8_t *d_img[CVH_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
   double *d_u[2] = {nullptr, nullptr};
   CvhState *d_state = nullptr;
-  CvhState *h_state = nullptr;  // pinned, two slots for pipelined polling
+  CvhState *h_state = nullptr;  // pinned, four slots for pipelined polling
   double *d_partials = nullptr;
   int partial_rows = 0;
   double *d_trace = nullptr;
@@ -32,16 +32,19 @@ struct cvh_context {
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
   int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
-  int wave_minw = 6;
+  int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1;
+  double *d_dummy = nullptr;
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
   double *d_atan = nullptr;
+  unsigned long long *d_dbg = nullptr;  // diagnostic stamps (option "debug_times")
+  size_t dbg_words = 0;
   double sum_img[CVH_MAX_CHANNELS] = {0, 0, 0};
   int tiles_x = 0, tiles_y = 0;
   int cur_base = 0;   // buffer that held u when the run counter was last reset
   int enqueued = 0;   // steps enqueued since then
   int steps_done = 0; // as of the last sync
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[2] = {nullptr, nullptr};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timing_open = false;
   float last_run_ms = 0.f, last_pm_ms = 0.f;
   char err[512] = {0};
@@ -119,9 +122,11 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->d_mask) (void)hipFree(c->d_mask);
   if (c->d_atan) (void)hipFree(c->d_atan);
+  if (c->d_dbg) (void)hipFree(c->d_dbg);
+  if (c->d_dummy) (void)hipFree(c->d_dummy);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  for (int k = 0; k < 2; ++k) if (c->evp[k]) (void)hipEventDestroy(c->evp[k]);
+  for (int k = 0; k < 4; ++k) if (c->evp[k]) (void)hipEventDestroy(c->evp[k]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -138,11 +143,11 @@ static int create_impl(cvh_context *c)
   for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc((void **)&c->d_u[k], c->n * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_state, sizeof(CvhState)));
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
-  HIPCHK(c, hipHostMalloc((void **)&c->h_state, 2 * sizeof(CvhState), hipHostMallocDefault));
-  memset(c->h_state, 0, 2 * sizeof(CvhState));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_state, 4 * sizeof(CvhState), hipHostMallocDefault));
+  memset(c->h_state, 0, 4 * sizeof(CvhState));
   int step_blocks = cvh_step_max_blocks(c->h, c->w);
   {
-    const int wave_blocks = (((c->w + cvh_wave_cols() - 1) / cvh_wave_cols()) * c->h + 3) / 4 + 1;  // strip_rows >= 1
+    const int wave_blocks = (((c->w + cvh_wave_cols() - 1) / cvh_wave_cols() + 3) / 4) * c->h + 1;  // strip_rows >= 1
     if (wave_blocks > step_blocks) step_blocks = wave_blocks;
   }
   {
@@ -162,9 +167,10 @@ static int create_impl(cvh_context *c)
   const int init_blocks = cvh_init_sum_blocks(c->h, c->w);
   c->partial_rows = step_blocks > init_blocks ? step_blocks : init_blocks;
   HIPCHK(c, hipMalloc((void **)&c->d_partials, (size_t)c->partial_rows * cvh_nsums(c->C) * sizeof(double)));
+  HIPCHK(c, hipMalloc((void **)&c->d_dummy, (size_t)(c->w > 64 ? c->w : 64) * sizeof(double)));
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
-  for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->evp[k], hipEventDisableTiming));
+  for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->evp[k], hipEventDisableTiming));
   snprintf(c->err, sizeof(c->err), "no error");
   return CVH_OK;
 }
@@ -228,6 +234,22 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "wave_occupancy")) {
     if (value < 5 || value > 8) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 5..8");
     c->wave_minw = (int)value;
+  } else if (!strcmp(key, "debug_times")) {
+    // diagnostic: per-wave start/end stamps of the wave kernel, read back with cvh_debug_read
+    if (c->d_dbg) { HIPCHK(c, hipFree(c->d_dbg)); c->d_dbg = nullptr; c->dbg_words = 0; }
+    if (value > 0) {
+      c->dbg_words = (size_t)c->partial_rows * 17 + 16;
+      HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
+      HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
+    }
+  } else if (!strcmp(key, "wave_imgv")) {
+    c->wave_imgv = value != 0;
+  } else if (!strcmp(key, "wave_sync")) {
+    c->wave_sync = value != 0;
+  } else if (!strcmp(key, "wave_prio")) {
+    c->wave_prio = value != 0;
+  } else if (!strcmp(key, "wave_lds_cap")) {
+    c->wave_lds_cap = value != 0;
   } else if (!strcmp(key, "strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "strip_rows must be >= 0");
     c->strip_rows = (int)value;
@@ -385,8 +407,8 @@ struct Geometry { int strip; int rows; int tiles_x, tiles_y, strip_rows, nblocks
 static Geometry resolve_geometry(const cvh_context *c)
 {
   Geometry g;
-  g.strip = c->kernel == 1 || (c->kernel == -1 && (c->w % 16) == 0);
-  if (c->kernel == 2) {
+  g.strip = c->kernel == 1;
+  if (c->kernel == 2 || c->kernel == -1) {  // default: the wave kernel (any width; fastest measured)
     // wave kernel: 63 output columns per wave, strip_rows rows per wave, 4 waves per workgroup;
     // one round of resident waves (wave_minw per SIMD)
     g.strip = 2;
@@ -394,14 +416,14 @@ static Geometry resolve_geometry(const cvh_context *c)
     g.tiles_x = (c->w + cvh_wave_cols() - 1) / cvh_wave_cols();
     int sr = c->strip_rows;
     if (sr <= 0) {
-      int nstrips = (c->num_cus * 4 * c->wave_minw) / g.tiles_x;
+      int nstrips = (c->num_cus * c->wave_minw) / ((g.tiles_x + 3) / 4);
       if (nstrips < 1) nstrips = 1;
       sr = (c->h + nstrips - 1) / nstrips;
       if (sr < 8) sr = 8;  // shorter strips only pay prologue overhead
     }
     g.strip_rows = sr;
     g.tiles_y = (c->h + sr - 1) / sr;
-    g.nblocks = (g.tiles_x * g.tiles_y + 3) / 4;
+    g.nblocks = ((g.tiles_x + 3) / 4) * g.tiles_y;  // 4 adjacent wave-columns per workgroup
     return g;
   }
   if (g.strip) {
@@ -453,6 +475,12 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->atan_tab = c->d_atan;
   a->atan2_tab = c->d_atan + 2 * CVH_ATAN_N;
   a->wave_minw = c->wave_minw;
+  a->wave_lds_cap = c->wave_lds_cap;
+  a->wave_prio = c->wave_prio;
+  a->wave_sync = c->wave_sync;
+  a->wave_imgv = c->wave_imgv;
+  a->dummy = c->d_dummy;
+  a->dbg_times = c->d_dbg;
   a->inv_eps = 1.0 / c->p.eps;
   a->dk1 = pi / c->p.eps;
   a->dk2 = pi * c->p.eps;
@@ -560,23 +588,32 @@ extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *l
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   rc = prepare(c);
   if (rc != CVH_OK) return rc;
-  // Chunks of sync_every launches; the stop flag of chunk k is read back while chunk k+1
-  // is already queued (launches behind a fired stop are no-ops on the device).
-  int slot = 0, pending = -1;
+  // Chunks of sync_every launches.  After each chunk the state is copied to a pinned slot; the
+  // host looks at a slot only once its event has fired (hipEventQuery, never blocking) and keeps
+  // up to kSlots chunks queued, so the GPU never waits for the host.  Launches queued behind a
+  // fired stop are no-ops on the device (sticky flag), so running ahead is harmless.
+  constexpr int kSlots = 4;
+  int head = 0, tail = 0;  // slots [tail, head) are in flight
   bool stopped = false;
   while (remaining > 0 && !stopped) {
+    if (head - tail == kSlots) {  // ring full: wait for the oldest
+      HIPCHK(c, hipEventSynchronize(c->evp[tail % kSlots]));
+    }
+    while (tail < head) {
+      const hipError_t q = hipEventQuery(c->evp[tail % kSlots]);
+      if (q == hipErrorNotReady) break;
+      if (q != hipSuccess) return fail(c, CVH_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+      stopped = stopped || c->h_state[tail % kSlots].stopped != 0;
+      ++tail;
+    }
+    if (stopped) break;
     const int chunk = (int)(remaining < c->sync_every ? remaining : c->sync_every);
     rc = enqueue_impl(c, chunk);
     if (rc != CVH_OK) return rc;
     remaining -= chunk;
-    HIPCHK(c, hipMemcpyAsync(&c->h_state[slot], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->evp[slot], c->stream));
-    if (pending >= 0) {
-      HIPCHK(c, hipEventSynchronize(c->evp[pending]));
-      stopped = c->h_state[pending].stopped != 0;
-    }
-    pending = slot;
-    slot ^= 1;
+    HIPCHK(c, hipMemcpyAsync(&c->h_state[head % kSlots], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->evp[head % kSlots], c->stream));
+    ++head;
   }
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
@@ -752,5 +789,18 @@ extern "C" int cvh_ppf_apply(double *data, int w, long start, long end, int op, 
   } while (0);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: %s", hipGetErrorString(e));
+  return CVH_OK;
+}
+
+// Diagnostic (not part of include/chanvese_hip.h): copies the stamp buffer of "debug_times".
+extern "C" int cvh_debug_read(cvh_context *c, unsigned long long *out, long max_words, long *words, int *nblocks)
+{
+  if (!c || !out || !words) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  long n = (long)c->dbg_words < max_words ? (long)c->dbg_words : max_words;
+  *words = n;
+  if (nblocks) *nblocks = resolve_geometry(c).nblocks;
+  if (n > 0 && c->d_dbg) HIPCHK(c, hipMemcpy(out, c->d_dbg, (size_t)n * 8, hipMemcpyDeviceToHost));
   return CVH_OK;
 }

@@ -28,12 +28,14 @@ namespace {
 constexpr int WCOLS = 63;   // output columns per wave
 constexpr int XPITCH = 66;  // exchange row: [0] = col-2 of lane 0, [1..64] = lanes, [65] = col+1 of lane 63
 constexpr int XSLOTS = 4;
+constexpr int IMGP = 80;     // bytes per row of the per-wave image tile (5 x 16-byte pieces)
 
 template <int C, bool FAST, bool LUT>
 struct WaveSmem {
   static constexpr int NS = cvh_nsums(C);
   static constexpr int off_x = 0;                                          // 4 waves x XSLOTS x XPITCH
-  static constexpr int off_red = off_x + 4 * XSLOTS * XPITCH;              // 4*NS
+  static constexpr int wave_doubles = XSLOTS * XPITCH + 64 + C * 4 * IMGP / 8;  // row slots + scratch + image tile
+  static constexpr int off_red = off_x + 4 * wave_doubles;                 // 4*NS
   static constexpr int off_fin = off_red + 4 * NS + (4 * NS) % 2;          // NS
   static constexpr int off_atan = off_fin + NS + NS % 2;                   // FAST: CVH_ATAN2_N
   static constexpr int off_lut = off_atan + (FAST ? CVH_ATAN2_N + 1 : 0);  // LUT: C*256
@@ -75,7 +77,7 @@ __device__ __forceinline__ double dpp_from_left(double v)
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int C, bool FAST, bool LUT, int MINW>
+template <int C, bool FAST, bool LUT, int MINW, bool IMGV>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStepArgs a)
 {
   using L = WaveSmem<C, FAST, LUT>;
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row arithmetic stays scalar
-  double *xs = smem + L::off_x + wave * (XSLOTS * XPITCH);
+  const unsigned long long t_start = a.dbg_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  double *xs = smem + L::off_x + wave * L::wave_doubles;
   const int h = a.h, w = a.w;
   if (tid == 0) *s_last = 0;
 
@@ -119,25 +122,31 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0;
 
-  // ---- this wave's strip
-  const int nwc = a.tiles_x;  // wave-columns per image row
-  const int gw = blockIdx.x * 4 + wave;
-  const int wc = gw % nwc, ws = gw / nwc;
+  // ---- this wave's strip: workgroup = 4 adjacent wave-columns of one strip
+  const int nwc = a.tiles_x;           // wave-columns per image row
+  const int nbc = (nwc + 3) >> 2;      // workgroups per strip
+  const int wc = (blockIdx.x % nbc) * 4 + wave, ws = blockIdx.x / nbc;
   const int s0 = ws * a.strip_rows;
-  if (s0 < h) {
+  const bool active = wc < nwc;        // the last workgroup of a strip may hold idle waves
+  const int col = WCOLS * wc - 1 + lane;                // lane 0 = left halo column
+  const bool lane_valid = active && (lane >= 1) && (col < w);
+  if (active) {
     const int s1 = (s0 + a.strip_rows) < h ? (s0 + a.strip_rows) : h;
-    const int col = WCOLS * wc - 1 + lane;              // lane 0 = left halo column
     const int colc = clampi(col, 0, w - 1);
-    const bool lane_valid = (lane >= 1) && (col < w);
-    const double vm = lane_valid ? 1.0 : 0.0;           // sums of halo / out-of-image lanes are exact zeros
     const double fx = (col <= 0) ? 0.0 : 1.0;           // kappa_x(i,0) = 0 (:371)
-    // the two extra halo columns of 4 consecutive rows, fetched by lanes 0..7
-    const int xrow = (lane >> 1) & 3, xside = lane & 1;
-    const int xcol = xside ? clampi(WCOLS * wc + 63, 0, w - 1) : clampi(WCOLS * wc - 2, 0, w - 1);
+    // Every vector-memory operation below is issued by ALL lanes on EVERY row (halo / out-of-
+    // image lanes are pointed at a dummy location instead of being masked off): the
+    // instruction stream is straight-line, so the compiler's counted vmcnt waits let the
+    // 4-row-deep load pipeline and the stores stay in flight.
     const bool xlane = lane < 8;
+    const int xrow = xlane ? (lane >> 1) & 3 : 0, xside = lane & 1;
+    const int xcol = !xlane ? colc : (xside ? clampi(WCOLS * wc + 63, 0, w - 1) : clampi(WCOLS * wc - 2, 0, w - 1));
     double *x_own = xs + 1 + lane;
-    double *x_ext = xs + xrow * XPITCH + (xside ? 65 : 0);
+    double *x_ext = xlane ? xs + xrow * XPITCH + (xside ? 65 : 0) : xs + XSLOTS * XPITCH + lane;  // lanes >= 8: scratch
     const double *x_w = xs + lane, *x_e = xs + lane + 2;
+    const unsigned ooff32 = (unsigned)colc * 8u;                  // byte offset of this lane's column in a row
+    const unsigned long long store_mask = __ballot(lane_valid);   // lanes that own an output pixel
+    unsigned long long exec_save = 0;
 
     // row base pointers are wave-uniform (scalar); the lane contributes a constant 32-bit offset
     auto U = [&](int r) -> double { const double *rp = a.u_in + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
@@ -149,14 +158,55 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     double um = U(s0 - 1), u0 = U(s0);
     double q[4];
     int im[C][4];
+    // Image samples.  IMGV (w % 16 == 0): the 64-byte row segments of 4 rows are fetched as
+    // 20 aligned 16-byte pieces by ONE load (lanes 0..19), staged in a per-wave LDS tile and
+    // read back as bytes: one vector-memory instruction per 4 rows instead of one 64 x 1-byte
+    // load per row (measured: the byte loads alone cost ~18 us of a 4096^2 launch).
+    unsigned char *simg = reinterpret_cast<unsigned char *>(xs + XSLOTS * XPITCH + 64);
+    const int icol0 = (WCOLS * wc - 1) & ~15;                      // 16-byte aligned start column (may be < 0)
+    const int ipiece = lane % 5, irow = lane / 5;                  // lanes 0..19: piece of row irow
+    const bool ilane = lane < 20;
+    int ipc = icol0 + 16 * ipiece;
+    ipc = ipc < 0 ? 0 : (ipc > w - 16 ? w - 16 : ipc);             // clamped pieces only feed clamped columns
+    const int ibyte = colc - icol0;                                // this lane's byte within a tile row (0..79)
+    typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+    uint4_t iq[C];
+    auto IMQ = [&](int r0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      q[k] = U(s0 + 1 + k);
+      for (int ch = 0; ch < C; ++ch)
+        iq[ch] = *reinterpret_cast<const uint4_t *>(a.img[ch] + (size_t)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * w + ipc);
+    };
+    auto IMTILE = [&]() {  // tile of the group whose pieces are in iq -> im[][]
+      if (ilane) {
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, s0 + k);
+        for (int ch = 0; ch < C; ++ch) {
+          // a piece clamped at the image edge lands where its columns are expected
+          const int dst = (icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0;
+          *reinterpret_cast<uint4_t *>(simg + (ch * 4 + irow) * IMGP + dst) = iq[ch];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) im[ch][k] = simg[(ch * 4 + k) * IMGP + ibyte];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = U(s0 + 1 + k);
+    if (IMGV) {
+      IMQ(s0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, s0 + k);
     }
-    double xq = xlane ? UX(s0) : 0.0;
-    if (xlane) *x_ext = xq;                     // extras of rows s0 .. s0+3 -> slots 0..3
+    double xq = UX(s0);
+    *x_ext = xq;                                // extras of rows s0 .. s0+3 -> slots 0..3
     x_own[0 * XPITCH] = u0;                     // row s0 -> slot 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -164,106 +214,162 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     double uw = x_w[0 * XPITCH], ue = x_e[0 * XPITCH];
     double ny_prev = normalised<FAST>(u0 - um, central(um2, u0));  // ny at row s0-1
 
-    for (int ib = s0; ib < s1; ib += 4) {
-      xq = xlane ? UX(ib + 4) : 0.0;            // extras of the NEXT four rows
+    // one row of the march; `live` (wave-uniform) is false only for rows past the strip end
+    auto row = [&](int i, int k, bool live) {
+      const double up = q[k];
+      // row i+1: publish this lane's value, fetch its neighbours for the next step
+      if (k == 3) *x_ext = xq;
+      x_own[((k + 1) & 3) * XPITCH] = up;
+      // the row buffer is exchanged between LANES of this wave: LDS operations of one wave
+      // execute in order, the fences only stop the compiler from reordering them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double uw_n = x_w[((k + 1) & 3) * XPITCH], ue_n = x_e[((k + 1) & 3) * XPITCH];
+      double nx, ny;
+      if (FAST) {
+        nx = normalised<true>(ue - u0, 0.5 * (ue - uw));
+        ny = normalised<true>(up - u0, 0.5 * (up - um));
+      } else {
+        nx = normalised<false>(ue - u0, central(uw, ue));  // :365-366
+        ny = normalised<false>(up - u0, central(um, up));  // :367-368
+      }
+      const double nxl = dpp_from_left(nx);
+      double kappa;
+      if (FAST) {
+        kappa = __builtin_fma(nx - nxl, fx, (i == 0) ? 0.0 : ny - ny_prev);
+      } else {
+        const double kx = (col <= 0) ? 0.0 : nx - nxl;                // :371
+        const double ky = (i == 0) ? 0.0 : ny - ny_prev;              // :372
+        kappa = kx + ky;                                              // :373
+      }
+      double Ik[C];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = ib + k;
-        const double up = q[k];
-        // row i+1: publish this lane's value, fetch its neighbours for the next step
-        if (k == 3) { if (xlane) *x_ext = xq; }
-        x_own[((k + 1) & 3) * XPITCH] = up;
-        // the row buffer is exchanged between LANES of this wave: LDS operations of one wave
-        // execute in order, the fences only stop the compiler from reordering them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double uw_n = x_w[((k + 1) & 3) * XPITCH], ue_n = x_e[((k + 1) & 3) * XPITCH];
-        if (i < s1) {
-          double nx, ny;
-          if (FAST) {
-            nx = normalised<true>(ue - u0, 0.5 * (ue - uw));
-            ny = normalised<true>(up - u0, 0.5 * (up - um));
-          } else {
-            nx = normalised<false>(ue - u0, central(uw, ue));  // :365-366
-            ny = normalised<false>(up - u0, central(um, up));  // :367-368
-          }
-          const double nxl = dpp_from_left(nx);
-          double kappa;
-          if (FAST) {
-            kappa = __builtin_fma(nx - nxl, fx, (i == 0) ? 0.0 : ny - ny_prev);
-          } else {
-            const double kx = (col <= 0) ? 0.0 : nx - nxl;                // :371
-            const double ky = (i == 0) ? 0.0 : ny - ny_prev;              // :372
-            kappa = kx + ky;                                              // :373
-          }
-          double Ik[C];
+      for (int ch = 0; ch < C; ++ch) Ik[ch] = (double)im[ch][k];
+      double ud, hv;
+      if (FAST) {
+        double reg;
+        if (LUT) {
+          reg = slut[im[0][k]];
 #pragma unroll
-          for (int ch = 0; ch < C; ++ch) Ik[ch] = (double)im[ch][k];
-          double ud, hv;
-          if (FAST) {
-            double reg;
-            if (LUT) {
-              reg = slut[im[0][k]];
-#pragma unroll
-              for (int ch = 1; ch < C; ++ch) reg += slut[ch * 256 + im[ch][k]];
-            } else {
-              reg = 0.0;
-#pragma unroll
-              for (int ch = 0; ch < C; ++ch) {
-                const double d1 = Ik[ch] - c1[ch], d2 = Ik[ch] - c2[ch];
-                reg += (d2 * d2) * l2[ch] - (d1 * d1) * l1[ch];
-              }
-              reg = __builtin_fma(reg, a.beta, a.gamma);
-            }
-            ud = __builtin_fma(kappa, a.alpha, reg);                      // :985
-            const double qd = __builtin_fma(u0, u0, eps2) * a.dk1;        // 1/delta_eps(u) = (pi/eps)(eps^2 + u^2)
-            const double r0 = __builtin_amdgcn_rcp(qd);
-            const double e = __builtin_fma(-qd, r0, 1.0);
-            ud = ud * __builtin_fma(__builtin_fma(e, e, e), r0, r0);      // :992
-          } else {
-            ud = 0.0;  // :965
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-              const double d1 = Ik[ch] - c1[ch], d2 = Ik[ch] - c2[ch];
-              const double vin = (d1 * d1) * l1[ch];   // :307-310
-              const double vout = (d2 * d2) * l2[ch];
-              ud += vout - vin;                         // :979
-            }
-            ud = kappa * a.alpha + ud * a.beta + a.gamma;   // :985
-            ud = ud * (eps / (kPi * (eps2 + u0 * u0)));      // :209, :992
-          }
-          const double un = u0 + ud;                         // :994
-          if (FAST) hv = heaviside_fast(un * a.inv_eps, satan);
-          else hv = heaviside_strict(un, eps);
-          if (lane_valid) { double *op = a.u_out + (size_t)i * w; op[colc] = un; }
-          const double hz = hv * vm, udz = ud * vm;
-          acc[0] += hz;
-          if (!FAST) acc[1] += (1 - hv) * vm;
+          for (int ch = 1; ch < C; ++ch) reg += slut[ch * 256 + im[ch][k]];
+        } else {
+          reg = 0.0;
 #pragma unroll
           for (int ch = 0; ch < C; ++ch) {
-            if (FAST) {
-              acc[2 + ch] = __builtin_fma(Ik[ch], hz, acc[2 + ch]);
-            } else {
-              acc[2 + ch] += Ik[ch] * hz;          // :276
-              acc[2 + C + ch] += Ik[ch] * ((1 - hv) * vm);
-            }
+            const double d1 = Ik[ch] - c1[ch], d2 = Ik[ch] - c2[ch];
+            reg += (d2 * d2) * l2[ch] - (d1 * d1) * l1[ch];
           }
-          if (FAST) acc[2 + 2 * C] = __builtin_fma(udz, udz, acc[2 + 2 * C]);
-          else acc[2 + 2 * C] += udz * udz;      // :993
-          ny_prev = ny;
+          reg = __builtin_fma(reg, a.beta, a.gamma);
         }
-        // refill the pipeline: row i+5 of u, row i+4 of the image
-        q[k] = U(i + 5);
+        ud = __builtin_fma(kappa, a.alpha, reg);                      // :985
+        const double qd = __builtin_fma(u0, u0, eps2) * a.dk1;        // 1/delta_eps(u) = (pi/eps)(eps^2 + u^2)
+        const double r0 = __builtin_amdgcn_rcp(qd);
+        const double e = __builtin_fma(-qd, r0, 1.0);
+        ud = ud * __builtin_fma(__builtin_fma(e, e, e), r0, r0);      // :992
+      } else {
+        ud = 0.0;  // :965
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          const double d1 = Ik[ch] - c1[ch], d2 = Ik[ch] - c2[ch];
+          const double vin = (d1 * d1) * l1[ch];   // :307-310
+          const double vout = (d2 * d2) * l2[ch];
+          ud += vout - vin;                         // :979
+        }
+        ud = kappa * a.alpha + ud * a.beta + a.gamma;   // :985
+        ud = ud * (eps / (kPi * (eps2 + u0 * u0)));      // :209, :992
+      }
+      const double un = u0 + ud;                         // :994
+      if (FAST) hv = heaviside_fast(un * a.inv_eps, satan);
+      else hv = heaviside_strict(un, eps);
+      {
+        // Valid lanes store the pixel (rows past the strip end go to the dummy row).  The store is
+        // written in assembly with the lane mask applied to EXEC by hand: an `if (lane_valid)`
+        // store becomes a control-flow diamond, and hipcc then waits vmcnt(0)-ish at every join,
+        // exposing the latency of the row pipeline; untracked by the compiler, this store only
+        // makes its counted waits slightly conservative (vmcnt is in issue order).
+        const double *ob = live ? a.u_out + (size_t)i * w : a.dummy;
+        asm volatile("s_mov_b64 %3, exec\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "s_nop 0\n\t"
+                     "global_store_dwordx2 %0, %1, %2\n\t"
+                     "s_mov_b64 exec, %3"
+                     : : "v"(ooff32), "v"(un), "s"(ob), "s"(exec_save), "s"(store_mask) : "memory");
+      }
+      if (live) {  // halo / out-of-image lanes are zeroed once after the loop
+        acc[0] += hv;
+        if (!FAST) acc[1] += (1 - hv);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          if (FAST) {
+            acc[2 + ch] = __builtin_fma(Ik[ch], hv, acc[2 + ch]);
+          } else {
+            acc[2 + ch] += Ik[ch] * hv;          // :276
+            acc[2 + C + ch] += Ik[ch] * (1 - hv);
+          }
+        }
+        if (FAST) acc[2 + 2 * C] = __builtin_fma(ud, ud, acc[2 + 2 * C]);
+        else acc[2 + 2 * C] += ud * ud;        // :993
+        ny_prev = ny;
+      }
+      // refill the pipeline: row i+5 of u, row i+4 of the image
+      q[k] = U(i + 5);
+      if (!IMGV) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, i + 4);
-        um = u0; u0 = up; uw = uw_n; ue = ue_n;
       }
+      um = u0; u0 = up; uw = uw_n; ue = ue_n;
+    };
+
+    int prio = 3;
+    if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
+    int ib = s0;
+    for (; ib < s1; ib += 4) {
+      if (a.wave_sync) __builtin_amdgcn_s_barrier();
+      if (a.wave_prio) {
+        // Equal-work waves drift apart under oldest-first issue arbitration and the tail then
+        // runs at 1-2 waves per SIMD.  Waves that are AHEAD lower their priority (by quarter of
+        // the strip), so laggards catch up and all waves finish together.
+        const int pq = ((s1 - ib) * 4 - 1) / (s1 - s0);  // 3,2,1,0 as the strip completes
+        if (pq != prio) {
+          prio = pq;
+          if (pq >= 3) __builtin_amdgcn_s_setprio(3);
+          else if (pq == 2) __builtin_amdgcn_s_setprio(2);
+          else if (pq == 1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      xq = UX(ib + 4);                          // extras of the NEXT four rows
+      if (IMGV) {
+        IMTILE();                               // image bytes of THIS group (requested a group ago)
+        IMQ(ib + 4);                            // request the next group's
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) row(ib + k, k, (ib + k) < s1);
     }
+    // exact: valid lanes are multiplied by 1, halo / out-of-image lanes by 0
+    const double vmask = lane_valid ? 1.0 : 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;
+  } else if (a.wave_sync) {                    // idle waves still meet the per-iteration barrier
+    const int s1i = (s0 + a.strip_rows) < h ? (s0 + a.strip_rows) : h;
+    for (int ib = s0; ib < s1i; ib += 4) __builtin_amdgcn_s_barrier();
   }
 
+  if (a.dbg_times && lane == 0) {  // diagnostic stamps: only ever written to their own buffer
+    unsigned long long *d = a.dbg_times + (size_t)(blockIdx.x * 4 + wave) * 4;
+    d[0] = t_start;
+    d[1] = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    d[2] = hwid;
+    d[3] = xcc;
+  }
   const double total = block_reduce<NS>(acc, sred);
   publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, s_last, gridDim.x);
+  if (a.dbg_times && tid == 0) a.dbg_times[(size_t)gridDim.x * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int C, bool FAST, bool LUT, int MINW>
@@ -271,7 +377,19 @@ hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
 {
   using L = WaveSmem<C, FAST, LUT>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
-  hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW>), dim3(a.nparts), dim3(CVH_BLOCK), L::bytes, s, a);
+  // Ask for 1/W of the CU's 160 KiB of LDS: the hardware can then place at most W workgroups on
+  // a CU, so a grid of <= W x CUs workgroups spreads evenly instead of packing some CUs fuller
+  // than others (the step is VALU-bound: the fullest CU sets the kernel time).
+  size_t lds = L::bytes;
+  if (a.wave_lds_cap) {
+    size_t cap = ((size_t)160 * 1024 / (size_t)(a.wave_minw > 2 ? a.wave_minw : 3)) & ~(size_t)511;
+    if (cap > 64 * 1024) cap = 64 * 1024;
+    if (cap > lds) lds = cap;
+  }
+  if (a.w % 16 == 0 && a.w >= 80 && a.wave_imgv)
+    hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  else
+    hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
   return hipGetLastError();
 }
 

@@ -54,6 +54,12 @@ struct CvhStepArgs {
   int strip_rows;                // rows per workgroup (strip kernel) / per wave (wave kernel)
   const double *atan2_tab;       // [CVH_ATAN2_N]: (pi/4 + atan((j-128)/128)) / pi
   int wave_minw;                 // waves per SIMD the wave kernel is compiled for (5..8)
+  unsigned long long *dbg_times; // diagnostic: per-wave {start, end, hw id} stamps (100 MHz), or null
+  double *dummy;                 // >= max(w, 64) doubles that nobody reads: target of masked-off lanes' stores
+  int wave_imgv;                 // wave kernel: 16-byte image pieces through LDS (w % 16 == 0)
+  int wave_sync;                 // wave kernel: workgroup barrier every 4 rows
+  int wave_prio;                 // progress-based s_setprio in the wave kernel
+  int wave_lds_cap;              // pad the LDS request so that at most wave_minw workgroups fit a CU
 };
 
 #define CVH_ATAN_N 129

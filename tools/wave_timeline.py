@@ -1,0 +1,39 @@
+"""Diagnostic: per-wave start/end stamps of one launch of the wave kernel (100 MHz realtime)."""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+import numpy as np
+from chan_vese_amd import capi, synth
+n = 4096
+ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
+ctx.set_option("kernel", 2)
+for kv in sys.argv[1:]:
+    k, v = kv.split("="); ctx.set_option(k, int(v))
+ctx.set_option("debug_times", 1)
+ctx.set_image([synth.disk(n)]); ctx.set_levelset(capi.checkerboard_host(n, n))
+ctx.run(5)
+L = capi.lib()
+buf = np.zeros(2_000_000, dtype=np.uint64); words = C.c_long(0); nb = C.c_int(0)
+L.cvh_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+L.cvh_debug_read(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size, C.byref(words), C.byref(nb))
+nb = nb.value
+w = buf[:nb * 16].reshape(nb * 4, 4)
+blk_end = buf[nb * 16: nb * 17]
+ok = w[:, 1] > 0
+t0 = w[ok, 0].min()
+st = (w[ok, 0] - t0) / 100.0; en = (w[ok, 1] - t0) / 100.0   # microseconds
+print("blocks", nb, "waves stamped", ok.sum())
+print("start us: min %.2f p50 %.2f p90 %.2f max %.2f" % (st.min(), np.median(st), np.percentile(st, 90), st.max()))
+print("end   us: min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f" % (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
+print("dur   us: min %.2f p50 %.2f max %.2f" % ((en - st).min(), np.median(en - st), (en - st).max()))
+print("block end (after publish/finalize) max us %.2f" % ((blk_end[blk_end > 0].max() - t0) / 100.0))
+xcc = w[ok, 3] & 0xf
+hw = w[ok, 2]
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key = xcc * 1000 + se * 100 + sh * 16 + cu
+u, cnt = np.unique(key, return_counts=True)
+print("distinct (xcc,se,sh,cu):", len(u), "waves per CU min/median/max:", cnt.min(), int(np.median(cnt)), cnt.max())
+hist, edges = np.histogram(en, bins=12)
+print("end-time histogram:", list(zip(np.round(edges[:-1], 1), hist)))
+late = st > 5
+print("waves starting later than 5 us:", late.sum())
+ctx.close()
