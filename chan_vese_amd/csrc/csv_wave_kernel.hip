@@ -104,19 +104,21 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   const double eps = a.eps;
   const double eps2 = eps * eps;
 
-  if (FAST) {
-    for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
-  }
-  if (LUT) {
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      const double v = (double)tid;
-      const double d1 = v - c1[k], d2 = v - c2[k];
-      const double reg = (d2 * d2) * l2[k] - (d1 * d1) * l1[k];
-      slut[k * 256 + tid] = (k == 0) ? __builtin_fma(reg, a.beta, a.gamma) : reg * a.beta;
+  // the tables are filled while the first rows are in flight: see fill_tables() below
+  auto fill_tables = [&]() {
+    if (FAST) {
+      for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
     }
-  }
-  __syncthreads();
+    if (LUT) {
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const double v = (double)tid;
+        const double d1 = v - c1[k], d2 = v - c2[k];
+        const double reg = (d2 * d2) * l2[k] - (d1 * d1) * l1[k];
+        slut[k * 256 + tid] = (k == 0) ? __builtin_fma(reg, a.beta, a.gamma) : reg * a.beta;
+      }
+    }
+  };
 
   double acc[NS];
 #pragma unroll
@@ -206,6 +208,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, s0 + k);
     }
     double xq = UX(s0);
+    fill_tables();                              // overlaps the prologue's loads
+    __syncthreads();
     *x_ext = xq;                                // extras of rows s0 .. s0+3 -> slots 0..3
     x_own[0 * XPITCH] = u0;                     // row s0 -> slot 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -351,7 +355,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     const double vmask = lane_valid ? 1.0 : 0.0;
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;
-  } else if (a.wave_sync) {                    // idle waves still meet the per-iteration barrier
+  } else {
+    fill_tables();
+    __syncthreads();
+  }
+  if (!active && a.wave_sync) {                // idle waves still meet the per-iteration barrier
     const int s1i = (s0 + a.strip_rows) < h ? (s0 + a.strip_rows) : h;
     for (int ib = s0; ib < s1i; ib += 4) __builtin_amdgcn_s_barrier();
   }

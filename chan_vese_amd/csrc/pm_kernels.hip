@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int PTW = 64, PTH = 16;
+constexpr int PTW = 64, PTH = 32;
 constexpr int IP = PTW + 4;  // pitch of the I tile
 constexpr int GP = PTW + 2;  // pitch of the g tile
 
@@ -27,14 +27,28 @@ __global__ __launch_bounds__(CVH_BLOCK) void pm_step_kernel(const CvhPmArgs a)
 
   // I tile: rows i0-2 .. i0+PTH+1, cols j0-2 .. j0+PTW+1; clamped indices = the reference's
   // neighbour clamps (:527-530)
-  for (int idx = tid; idx < (PTH + 4) * IP; idx += CVH_BLOCK) {
-    const int r = idx / IP, c = idx - r * IP;
-    const int gi = clampi(i0 - 2 + r, 0, h - 1), gj = clampi(j0 - 2 + c, 0, w - 1);
-    sI[idx] = a.in[(size_t)gi * w + gj];
+  {
+    // all loads of the tile are issued before the first LDS write (no serialised round trips)
+    constexpr int N = (PTH + 4) * IP, NRD = (N + CVH_BLOCK - 1) / CVH_BLOCK;
+    double v[NRD];
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int idx = rd * CVH_BLOCK + tid;
+      const int q = idx < N ? idx : N - 1;
+      const int r = q / IP, c = q - r * IP;
+      const int gi = clampi(i0 - 2 + r, 0, h - 1), gj = clampi(j0 - 2 + c, 0, w - 1);
+      v[rd] = a.in[(size_t)gi * w + gj];
+    }
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int idx = rd * CVH_BLOCK + tid;
+      if (idx < N) sI[idx] = v[rd];
+    }
   }
   __syncthreads();
 
   // g on rows i0-1 .. i0+PTH, cols j0-1 .. j0+PTW (:513-522)
+#pragma unroll 3
   for (int idx = tid; idx < (PTH + 2) * GP; idx += CVH_BLOCK) {
     const int r = idx / GP, c = idx - r * GP;
     const int gi = i0 - 1 + r, gj = j0 - 1 + c;

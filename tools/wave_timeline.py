@@ -3,7 +3,7 @@ import ctypes as C, sys
 sys.path.insert(0, '.')
 import numpy as np
 from chan_vese_amd import capi, synth
-n = 4096
+n = int(__import__("os").environ.get("N", "4096"))
 ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
 ctx.set_option("kernel", 2)
 for kv in sys.argv[1:]:
