@@ -32,7 +32,7 @@ struct cvh_context {
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
   int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
-  int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_store = 0;
+  int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_depth = 4;
   double *d_dummy = nullptr;
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
@@ -232,7 +232,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
   } else if (!strcmp(key, "wave_occupancy")) {
-    if (value < 5 || value > 8) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 5..8");
+    if (value < 4 || value > 8) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 4..8");
     c->wave_minw = (int)value;
   } else if (!strcmp(key, "debug_times")) {
     // diagnostic: per-wave start/end stamps of the wave kernel, read back with cvh_debug_read
@@ -242,9 +242,9 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
       HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
       HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
     }
-  } else if (!strcmp(key, "wave_store")) {
-    if (value < 0 || value > 2) return fail(c, CVH_ERR_ARG, "wave_store must be 0 (plain), 1 (nt) or 2 (sc1)");
-    c->wave_store = (int)value;
+  } else if (!strcmp(key, "wave_depth")) {
+    if (value != 4 && value != 8) return fail(c, CVH_ERR_ARG, "wave_depth must be 4 or 8");
+    c->wave_depth = (int)value;
   } else if (!strcmp(key, "wave_imgv")) {
     c->wave_imgv = value != 0;
   } else if (!strcmp(key, "wave_sync")) {
@@ -481,7 +481,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->wave_lds_cap = c->wave_lds_cap;
   a->wave_prio = c->wave_prio;
   a->wave_sync = c->wave_sync;
-  a->wave_store = c->wave_store;
+  a->wave_depth = c->wave_depth;
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;
   a->dbg_times = c->d_dbg;

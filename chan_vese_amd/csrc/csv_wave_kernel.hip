@@ -52,6 +52,20 @@ struct WaveSmem {
 __device__ __forceinline__ double heaviside_fast(double x, const double *tab /*LDS, CVH_ATAN2_N*/)
 {
   const double a = fmin(fabs(x), 1e300);
+  // Far field, decided per WAVE (uniform branch): with the reference's default time step the
+  // level set sits at |u| >> 64 everywhere after a handful of iterations.  There
+  // atan(a) = pi/2 - atan(1/a) and the series of atan(t), t <= 1/64, truncated after t^7/7
+  // (next term < 7e-18) needs one reciprocal and no table.
+  if (__builtin_amdgcn_ballot_w64(a < 64.0) == 0ull) {
+    const double r0 = __builtin_amdgcn_rcp(a);
+    const double t = __builtin_fma(__builtin_fma(-a, r0, 1.0), r0, r0);
+    const double t2 = t * t;
+    double p = __builtin_fma(t2, -1.0 / 7.0, 0.2);
+    p = __builtin_fma(p, t2, -1.0 / 3.0);
+    const double s = __builtin_fma(t * t2, p, t);                    // atan(1/a)
+    const double atpi = __builtin_fma(-s, 1.0 / kPi, 0.5);           // (pi/2 - s)/pi
+    return 0.5 + __builtin_copysign(atpi, x);
+  }
   const double n = a - 1.0, d = a + 1.0;
   const double y0 = n * __builtin_amdgcn_rcp(d);
   const double fi = __builtin_rint(y0 * 128.0);
@@ -77,7 +91,7 @@ __device__ __forceinline__ double dpp_from_left(double v)
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int C, bool FAST, bool LUT, int MINW, bool IMGV>
+template <int C, bool FAST, bool LUT, int MINW, bool IMGV, int G>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStepArgs a)
 {
   using L = WaveSmem<C, FAST, LUT>;
@@ -148,7 +162,6 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     const double *x_w = xs + lane, *x_e = xs + lane + 2;
     const unsigned ooff32 = (unsigned)colc * 8u;                  // byte offset of this lane's column in a row
     const unsigned long long store_mask = __ballot(lane_valid);   // lanes that own an output pixel
-    unsigned long long exec_save = 0;
 
     // row base pointers are wave-uniform (scalar); the lane contributes a constant 32-bit offset
     auto U = [&](int r) -> double { const double *rp = a.u_in + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     // ---- prologue
     const double um2 = U(s0 - 2);
     double um = U(s0 - 1), u0 = U(s0);
-    double q[4];
+    double q[4 * G];   // rows i+1 .. i+4G of this lane's column: the load pipeline (4G rows deep)
     int im[C][4];
     // Image samples.  IMGV (w % 16 == 0): the 64-byte row segments of 4 rows are fetched as
     // 20 aligned 16-byte pieces by ONE load (lanes 0..19), staged in a per-wave LDS tile and
@@ -172,19 +185,19 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     ipc = ipc < 0 ? 0 : (ipc > w - 16 ? w - 16 : ipc);             // clamped pieces only feed clamped columns
     const int ibyte = colc - icol0;                                // this lane's byte within a tile row (0..79)
     typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-    uint4_t iq[C];
-    auto IMQ = [&](int r0) {
+    uint4_t iq[G][C];
+    auto IMQ = [&](int g, int r0) {
 #pragma unroll
       for (int ch = 0; ch < C; ++ch)
-        iq[ch] = *reinterpret_cast<const uint4_t *>(a.img[ch] + (size_t)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * w + ipc);
+        iq[g][ch] = *reinterpret_cast<const uint4_t *>(a.img[ch] + (size_t)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * w + ipc);
     };
-    auto IMTILE = [&]() {  // tile of the group whose pieces are in iq -> im[][]
+    auto IMTILE = [&](int g) {  // tile of the group whose pieces are in iq[g] -> im[][]
       if (ilane) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
           // a piece clamped at the image edge lands where its columns are expected
           const int dst = (icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0;
-          *reinterpret_cast<uint4_t *>(simg + (ch * 4 + irow) * IMGP + dst) = iq[ch];
+          *reinterpret_cast<uint4_t *>(simg + (ch * 4 + irow) * IMGP + dst) = iq[g][ch];
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -198,19 +211,26 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       __builtin_amdgcn_wave_barrier();
     };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = U(s0 + 1 + k);
+    for (int k = 0; k < 4 * G; ++k) q[k] = U(s0 + 1 + k);
     if (IMGV) {
-      IMQ(s0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) IMQ(g, s0 + 4 * g);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, s0 + k);
     }
-    double xq = UX(s0);
-    fill_tables();                              // overlaps the prologue's loads
-    __syncthreads();
-    *x_ext = xq;                                // extras of rows s0 .. s0+3 -> slots 0..3
+    double xq[G];
+    {
+      const double x0 = UX(s0);
+#pragma unroll
+      for (int g = 1; g < G; ++g) xq[g] = UX(s0 + 4 * g);  // xq[g]: extras of rows base+4g .. (g >= 1)
+      xq[0] = UX(s0 + 4 * G);                               // xq[0]: extras of the next iteration's first group
+      fill_tables();                            // overlaps the prologue's loads
+      __syncthreads();
+      *x_ext = x0;                              // extras of rows s0 .. s0+3 -> slots 0..3
+    }
     x_own[0 * XPITCH] = u0;                     // row s0 -> slot 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -219,10 +239,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     double ny_prev = normalised<FAST>(u0 - um, central(um2, u0));  // ny at row s0-1
 
     // one row of the march; `live` (wave-uniform) is false only for rows past the strip end
-    auto row = [&](int i, int k, bool live) {
-      const double up = q[k];
+    auto row = [&](int i, int g, int k, bool live) {
+      const double up = q[4 * g + k];
       // row i+1: publish this lane's value, fetch its neighbours for the next step
-      if (k == 3) *x_ext = xq;
+      if (k == 3) *x_ext = xq[(g + 1) % G];     // extras of the next group's rows
       x_own[((k + 1) & 3) * XPITCH] = up;
       // the row buffer is exchanged between LANES of this wave: LDS operations of one wave
       // execute in order, the fences only stop the compiler from reordering them
@@ -293,12 +313,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         // exposing the latency of the row pipeline; untracked by the compiler, this store only
         // makes its counted waits slightly conservative (vmcnt is in issue order).
         const double *ob = live ? a.u_out + (size_t)i * w : a.dummy;
-        asm volatile("s_mov_b64 %3, exec\n\t"
+        unsigned long long exec_keep;  // early-clobber OUTPUT: the asm writes it before reading its inputs
+        asm volatile("s_mov_b64 %0, exec\n\t"
                      "s_mov_b64 exec, %4\n\t"
-                     "s_nop 0\n\t"
-                     "global_store_dwordx2 %0, %1, %2\n\t"
-                     "s_mov_b64 exec, %3"
-                     : : "v"(ooff32), "v"(un), "s"(ob), "s"(exec_save), "s"(store_mask) : "memory");
+                     "s_nop 4\n\t"
+                     "global_store_dwordx2 %1, %2, %3\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(exec_keep) : "v"(ooff32), "v"(un), "s"(ob), "s"(store_mask) : "memory");
       }
       if (live) {  // halo / out-of-image lanes are zeroed once after the loop
         acc[0] += hv;
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         ny_prev = ny;
       }
       // refill the pipeline: row i+5 of u, row i+4 of the image
-      q[k] = U(i + 5);
+      q[4 * g + k] = U(i + 1 + 4 * G);
       if (!IMGV) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, i + 4);
@@ -327,9 +348,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 
     int prio = 3;
     if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
-    int ib = s0;
-    for (; ib < s1; ib += 4) {
+    for (int ib0 = s0; ib0 < s1; ib0 += 4 * G) {
+#pragma unroll
+     for (int g = 0; g < G; ++g) {
+      const int ib = ib0 + 4 * g;
+      if (ib >= s1 && !a.wave_sync) break;
       if (a.wave_sync) __builtin_amdgcn_s_barrier();
+      if (ib >= s1) continue;
       if (a.wave_prio) {
         // Equal-work waves drift apart under oldest-first issue arbitration and the tail then
         // runs at 1-2 waves per SIMD.  Waves that are AHEAD lower their priority (by quarter of
@@ -343,13 +368,15 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
           else __builtin_amdgcn_s_setprio(0);
         }
       }
-      xq = UX(ib + 4);                          // extras of the NEXT four rows
       if (IMGV) {
-        IMTILE();                               // image bytes of THIS group (requested a group ago)
-        IMQ(ib + 4);                            // request the next group's
+        IMTILE(g);                              // image bytes of THIS group (requested G groups ago)
+        IMQ(g, ib + 4 * G);                     // request the group 4G rows ahead
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) row(ib + k, k, (ib + k) < s1);
+      for (int k = 0; k < 4; ++k) row(ib + k, g, k, (ib + k) < s1);
+      // extras 4G rows ahead of the group that follows (consumed at its k == 3 ... one turn later)
+      xq[(g + 1) % G] = UX(ib + 4 + 4 * G);
+     }
     }
     // exact: valid lanes are multiplied by 1, halo / out-of-image lanes by 0
     const double vmask = lane_valid ? 1.0 : 0.0;
@@ -394,10 +421,14 @@ hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
     if (cap > 64 * 1024) cap = 64 * 1024;
     if (cap > lds) lds = cap;
   }
-  if (a.w % 16 == 0 && a.w >= 80 && a.wave_imgv)
-    hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-  else
-    hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  const bool imgv = a.w % 16 == 0 && a.w >= 80 && a.wave_imgv;
+  if (a.wave_depth >= 8) {
+    if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, 2>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, 2>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  } else {
+    if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -408,7 +439,8 @@ hipError_t launch_wave_c(const CvhStepArgs &a, int fast, hipStream_t s)
   if (a.wave_minw >= 8) return a.use_lut ? launch_wave_v<C, true, true, 8>(a, s) : launch_wave_v<C, true, false, 8>(a, s);
   if (a.wave_minw == 7) return a.use_lut ? launch_wave_v<C, true, true, 7>(a, s) : launch_wave_v<C, true, false, 7>(a, s);
   if (a.wave_minw == 6) return a.use_lut ? launch_wave_v<C, true, true, 6>(a, s) : launch_wave_v<C, true, false, 6>(a, s);
-  return a.use_lut ? launch_wave_v<C, true, true, 5>(a, s) : launch_wave_v<C, true, false, 5>(a, s);
+  if (a.wave_minw == 5) return a.use_lut ? launch_wave_v<C, true, true, 5>(a, s) : launch_wave_v<C, true, false, 5>(a, s);
+  return a.use_lut ? launch_wave_v<C, true, true, 4>(a, s) : launch_wave_v<C, true, false, 4>(a, s);
 }
 
 }  // namespace

@@ -57,7 +57,7 @@ struct CvhStepArgs {
   unsigned long long *dbg_times; // diagnostic: per-wave {start, end, hw id} stamps (100 MHz), or null
   double *dummy;                 // >= max(w, 64) doubles that nobody reads: target of masked-off lanes' stores
   int wave_imgv;                 // wave kernel: 16-byte image pieces through LDS (w % 16 == 0)
-  int wave_store;                // wave kernel store policy: 0 plain, 1 nt, 2 sc1
+  int wave_depth;                // wave kernel: rows of u kept in flight per lane (4 or 8)
   int wave_sync;                 // wave kernel: workgroup barrier every 4 rows
   int wave_prio;                 // progress-based s_setprio in the wave kernel
   int wave_lds_cap;              // pad the LDS request so that at most wave_minw workgroups fit a CU
