@@ -140,7 +140,9 @@ static int create_impl(cvh_context *c)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->num_cus = cus;
   }
   for (int k = 0; k < c->C; ++k) HIPCHK(c, hipMalloc((void **)&c->d_img[k], c->n));
-  for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc((void **)&c->d_u[k], c->n * sizeof(double)));
+  // 64 doubles of slack behind each level-set buffer: the wave kernel parks the stores of lanes
+  // that own no pixel there (see csv_wave_kernel.hip)
+  for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc((void **)&c->d_u[k], (c->n + 64) * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_state, sizeof(CvhState)));
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_state, 4 * sizeof(CvhState), hipHostMallocDefault));
@@ -411,7 +413,9 @@ static Geometry resolve_geometry(const cvh_context *c)
 {
   Geometry g;
   g.strip = c->kernel == 1;
-  if (c->kernel == 2 || c->kernel == -1) {  // default: the wave kernel (any width; fastest measured)
+  // default: the wave kernel (any width; fastest measured); it addresses stores with 32-bit byte
+  // offsets from the buffer start, so images of 2^29 pixels or more use the tile kernel
+  if ((c->kernel == 2 || c->kernel == -1) && c->n < ((size_t)1 << 29) - 64) {
     // wave kernel: 63 output columns per wave, strip_rows rows per wave, 4 waves per workgroup;
     // one round of resident waves (wave_minw per SIMD)
     g.strip = 2;

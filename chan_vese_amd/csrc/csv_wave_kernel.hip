@@ -164,14 +164,25 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     const unsigned long long store_mask = __ballot(lane_valid);   // lanes that own an output pixel
 
     // row base pointers are wave-uniform (scalar); the lane contributes a constant 32-bit offset
+#ifdef CVH_ABLATE_MEMORY   // diagnostic build: no global loads/stores in the loop (results are wrong)
+    auto U = [&](int r) -> double { return (double)(r & 15) * 0.37 + (double)colc * 0.001; };
+#else
     auto U = [&](int r) -> double { const double *rp = a.u_in + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
+#endif
     auto UX = [&](int r0) -> double { return a.u_in[(size_t)clampi(r0 + xrow, 0, h - 1) * w + xcol]; };
     auto IM = [&](int k, int r) -> int { const uint8_t *rp = a.img[k] + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
 
     // ---- prologue
+    // Rows of this lane's column live in a register ring.  G == 2: ring of 8, slot (t & 7) holds
+    // row s0+1+t at step t (`up`), `u0` and `um` are slots t-1 and t-2, and the slot of the row
+    // that has just died is refilled with the row 8 ahead: every loop-carried value keeps its
+    // register from one iteration to the next, so the loop back-edge needs no copies of
+    // in-flight loads (hipcc otherwise waits for them there and drains the pipeline every
+    // iteration).  G == 1 keeps the shifted um/u0/up form.
+    constexpr bool RING8 = (G == 2);
     const double um2 = U(s0 - 2);
     double um = U(s0 - 1), u0 = U(s0);
-    double q[4 * G];   // rows i+1 .. i+4G of this lane's column: the load pipeline (4G rows deep)
+    double q[4 * G];
     int im[C][4];
     // Image samples.  IMGV (w % 16 == 0): the 64-byte row segments of 4 rows are fetched as
     // 20 aligned 16-byte pieces by ONE load (lanes 0..19), staged in a per-wave LDS tile and
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     };
 #pragma unroll
     for (int k = 0; k < 4 * G; ++k) q[k] = U(s0 + 1 + k);
+    if (RING8) { q[6] = um; q[7] = u0; }       // slots of rows s0-1, s0 (rows s0+7, s0+8 are requested at steps 0, 1)
     if (IMGV) {
 #pragma unroll
       for (int g = 0; g < G; ++g) IMQ(g, s0 + 4 * g);
@@ -240,7 +252,9 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 
     // one row of the march; `live` (wave-uniform) is false only for rows past the strip end
     auto row = [&](int i, int g, int k, bool live) {
-      const double up = q[4 * g + k];
+      const int t = 4 * g + k;                  // step within the loop body (static after unrolling)
+      const double up = q[t];
+      if (RING8) { u0 = q[(t + 7) & 7]; um = q[(t + 6) & 7]; }
       // row i+1: publish this lane's value, fetch its neighbours for the next step
       if (k == 3) *x_ext = xq[(g + 1) % G];     // extras of the next group's rows
       x_own[((k + 1) & 3) * XPITCH] = up;
@@ -250,6 +264,16 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const double uw_n = x_w[((k + 1) & 3) * XPITCH], ue_n = x_e[((k + 1) & 3) * XPITCH];
+#ifdef CVH_ABLATE_COMPUTE  // diagnostic build: the memory/LDS instruction stream without the arithmetic
+      if (FAST) {
+        const double un_ = u0 + (up + um + uw + ue) * 1e-30 + (double)im[0][k] * 1e-30;
+        if (lane_valid) (live ? a.u_out + (size_t)i * w : a.dummy)[colc] = un_;
+        acc[0] += un_;
+        q[(t + 6) & 7] = U(i + 7);
+        uw = uw_n; ue = ue_n;
+        return;
+      }
+#endif
       double nx, ny;
       if (FAST) {
         nx = normalised<true>(ue - u0, 0.5 * (ue - uw));
@@ -309,11 +333,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       {
         // Valid lanes store the pixel (rows past the strip end go to the dummy row).  The store is
         // written in assembly with the lane mask applied to EXEC by hand: an `if (lane_valid)`
-        // store becomes a control-flow diamond, and hipcc then waits vmcnt(0)-ish at every join,
-        // exposing the latency of the row pipeline; untracked by the compiler, this store only
-        // makes its counted waits slightly conservative (vmcnt is in issue order).
+        // store becomes a control-flow diamond and hipcc then waits for (nearly) all outstanding
+        // loads at every join.  Measured alternatives (profiles/README.md): an all-lane store to a
+        // slack area (compiler-visible, exact counted waits) is 4-5 us slower per launch.
+        // hipcc pads no hazards inside asm: `ob` may have been written by the SALU instruction
+        // just before (5 wait states before a VMEM read on gfx9), hence the s_nop 4.
         const double *ob = live ? a.u_out + (size_t)i * w : a.dummy;
-        unsigned long long exec_keep;  // early-clobber OUTPUT: the asm writes it before reading its inputs
+        unsigned long long exec_keep;  // early-clobber OUTPUT: written before the inputs are read
         asm volatile("s_mov_b64 %0, exec\n\t"
                      "s_mov_b64 exec, %4\n\t"
                      "s_nop 4\n\t"
@@ -338,12 +364,14 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         ny_prev = ny;
       }
       // refill the pipeline: row i+5 of u, row i+4 of the image
-      q[4 * g + k] = U(i + 1 + 4 * G);
+      if (RING8) q[(t + 6) & 7] = U(i + 7);     // row i-1 is dead: its slot takes the row 8 below it
+      else q[t] = U(i + 1 + 4 * G);
       if (!IMGV) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, i + 4);
       }
-      um = u0; u0 = up; uw = uw_n; ue = ue_n;
+      if (!RING8) { um = u0; u0 = up; }
+      uw = uw_n; ue = ue_n;
     };
 
     int prio = 3;
