@@ -73,6 +73,8 @@ struct CvhPmArgs {
   int tiles_x, tiles_y;
   double K2;  // K*K (:520)
   double L;
+  double invK2, L4;  // FAST flavour: 1/K^2, L/4
+  int fast;
 };
 
 // ---- launchers (csv_kernels.hip / pm_kernels.hip / misc_kernels.hip) ----

@@ -6,7 +6,9 @@
 // ring once per cell into LDS, then updates its 16 x 64 pixels.  FP64 state ping-pongs in
 // HBM; the uint8 rounding (:551) is only observable after the last step and is done by
 // pm_store_kernel (round-half-even, clamp).
-#include "cvh_internal.h"
+#include "csv_device.h"
+
+using cvh_dev::rcp_refined;
 
 namespace {
 
@@ -14,8 +16,12 @@ constexpr int PTW = 64, PTH = 32;
 constexpr int IP = PTW + 4;  // pitch of the I tile
 constexpr int GP = PTW + 2;  // pitch of the g tile
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+using cvh_dev::clampi;
 
+// FAST: reciprocal + cubic refinement (<= 1 ulp) and FMAs instead of the two IEEE divisions; the
+// final uint8 image can then differ from the strict one only where a value sits within ~1e-13 of a
+// rounding boundary.  STRICT rounds every operation as the reference's x86-64 build.
+template <bool FAST>
 __global__ __launch_bounds__(CVH_BLOCK) void pm_step_kernel(const CvhPmArgs a)
 {
   __shared__ double sI[(PTH + 4) * IP];
@@ -61,7 +67,8 @@ __global__ __launch_bounds__(CVH_BLOCK) void pm_step_kernel(const CvhPmArgs a)
       const double sm = p[-IP - 1] + p[-IP] * 2 + p[-IP + 1];
       const double sp = p[IP - 1] + p[IP] * 2 + p[IP + 1];
       const double gy = sp - sm;
-      g = 1.0 / (1.0 + (gx * gx + gy * gy) / a.K2);
+      if (FAST) g = rcp_refined(__builtin_fma(__builtin_fma(gx, gx, gy * gy), a.invK2, 1.0));
+      else g = 1.0 / (1.0 + (gx * gx + gy * gy) / a.K2);
     }
     sg[idx] = g;
   }
@@ -77,9 +84,17 @@ __global__ __launch_bounds__(CVH_BLOCK) void pm_step_kernel(const CvhPmArgs a)
       const double *p = &sI[(r + 2) * IP + (tx + 2)];
       const double *g = &sg[(r + 1) * GP + (tx + 1)];
       const double I0 = p[0], c0 = g[0];
-      const double s = (g[GP] + c0) * (p[IP] - I0) + (g[1] + c0) * (p[1] - I0) +
-                       (g[-GP] + c0) * (p[-IP] - I0) + (g[-1] + c0) * (p[-1] - I0);
-      a.out[(size_t)gi * w + gj] = I0 + a.L * s / 4;  // :544-547
+      if (FAST) {
+        double s = (g[GP] + c0) * (p[IP] - I0);
+        s = __builtin_fma(g[1] + c0, p[1] - I0, s);
+        s = __builtin_fma(g[-GP] + c0, p[-IP] - I0, s);
+        s = __builtin_fma(g[-1] + c0, p[-1] - I0, s);
+        a.out[(size_t)gi * w + gj] = __builtin_fma(a.L4, s, I0);
+      } else {
+        const double s = (g[GP] + c0) * (p[IP] - I0) + (g[1] + c0) * (p[1] - I0) +
+                         (g[-GP] + c0) * (p[-IP] - I0) + (g[-1] + c0) * (p[-1] - I0);
+        a.out[(size_t)gi * w + gj] = I0 + a.L * s / 4;  // :544-547
+      }
     }
   }
 }
@@ -120,7 +135,8 @@ hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hip
 
 hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s)
 {
-  hipLaunchKernelGGL(pm_step_kernel, dim3(a.tiles_x * a.tiles_y), dim3(CVH_BLOCK), 0, s, a);
+  if (a.fast) hipLaunchKernelGGL(pm_step_kernel<true>, dim3(a.tiles_x * a.tiles_y), dim3(CVH_BLOCK), 0, s, a);
+  else hipLaunchKernelGGL(pm_step_kernel<false>, dim3(a.tiles_x * a.tiles_y), dim3(CVH_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
