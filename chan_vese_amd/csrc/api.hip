@@ -423,7 +423,8 @@ static Geometry resolve_geometry(const cvh_context *c)
     g.tiles_x = (c->w + cvh_wave_cols() - 1) / cvh_wave_cols();
     int sr = c->strip_rows;
     if (sr <= 0) {
-      int nstrips = (c->num_cus * c->wave_minw) / ((g.tiles_x + 3) / 4);
+      const int occ = c->C == 3 ? 3 : c->wave_minw;  // the 3-channel kernel is compiled for 3 waves/SIMD
+      int nstrips = (c->num_cus * occ) / ((g.tiles_x + 3) / 4);
       if (nstrips < 1) nstrips = 1;
       sr = (c->h + nstrips - 1) / nstrips;
       if (sr < 8) sr = 8;  // shorter strips only pay prologue overhead

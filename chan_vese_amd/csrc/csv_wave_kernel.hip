@@ -463,12 +463,16 @@ hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
 template <int C>
 hipError_t launch_wave_c(const CvhStepArgs &a, int fast, hipStream_t s)
 {
-  if (!fast) return launch_wave_v<C, false, false, 4>(a, s);
+  if (!fast) return launch_wave_v<C, false, false, (C == 1 ? 4 : 2)>(a, s);
+  if constexpr (C == 3) {  // 9 accumulators, 3 image tiles: fits 168 registers (3 waves/SIMD) without spilling
+    return a.use_lut ? launch_wave_v<C, true, true, 3>(a, s) : launch_wave_v<C, true, false, 3>(a, s);
+  } else {
   if (a.wave_minw >= 8) return a.use_lut ? launch_wave_v<C, true, true, 8>(a, s) : launch_wave_v<C, true, false, 8>(a, s);
   if (a.wave_minw == 7) return a.use_lut ? launch_wave_v<C, true, true, 7>(a, s) : launch_wave_v<C, true, false, 7>(a, s);
   if (a.wave_minw == 6) return a.use_lut ? launch_wave_v<C, true, true, 6>(a, s) : launch_wave_v<C, true, false, 6>(a, s);
   if (a.wave_minw == 5) return a.use_lut ? launch_wave_v<C, true, true, 5>(a, s) : launch_wave_v<C, true, false, 5>(a, s);
   return a.use_lut ? launch_wave_v<C, true, true, 4>(a, s) : launch_wave_v<C, true, false, 4>(a, s);
+  }
 }
 
 }  // namespace
