@@ -32,8 +32,11 @@ struct cvh_context {
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
   int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
+  int pm_kernel = 1;    // 0 tile kernel, 1 wave kernel
+  int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_depth = 4;
   double *d_dummy = nullptr;
+  int *h_status = nullptr;  // pinned + mapped: {steps_done, stopped} written by the device
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
   double *d_atan = nullptr;
@@ -124,6 +127,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_atan) (void)hipFree(c->d_atan);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
+  if (c->h_status) (void)hipHostFree(c->h_status);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 4; ++k) if (c->evp[k]) (void)hipEventDestroy(c->evp[k]);
@@ -170,6 +174,8 @@ static int create_impl(cvh_context *c)
   c->partial_rows = step_blocks > init_blocks ? step_blocks : init_blocks;
   HIPCHK(c, hipMalloc((void **)&c->d_partials, (size_t)c->partial_rows * cvh_nsums(c->C) * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_dummy, (size_t)(c->w > 64 ? c->w : 64) * sizeof(double)));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_status, 64, hipHostMallocMapped));
+  c->h_status[0] = 0; c->h_status[1] = 0;
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->evp[k], hipEventDisableTiming));
@@ -233,6 +239,11 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value < -1 || value > 2) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile), 1 (strip) or 2 (wave)");
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
+  } else if (!strcmp(key, "pm_kernel")) {
+    c->pm_kernel = value != 0;
+  } else if (!strcmp(key, "pm_strip_rows")) {
+    if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
+    c->pm_strip_rows = (int)value;
   } else if (!strcmp(key, "wave_occupancy")) {
     if (value < 4 || value > 8) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 4..8");
     c->wave_minw = (int)value;
@@ -348,6 +359,7 @@ static int reset_run_impl(cvh_context *c)
   const int zeros[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(&c->d_state->steps_done, zeros, sizeof(zeros), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->h_status[0] = 0; c->h_status[1] = 0;
   return CVH_OK;
 }
 
@@ -489,6 +501,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->wave_depth = c->wave_depth;
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;
+  a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
   a->inv_eps = 1.0 / c->p.eps;
   a->dk1 = pi / c->p.eps;
@@ -607,32 +620,24 @@ extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *l
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   rc = prepare(c);
   if (rc != CVH_OK) return rc;
-  // Chunks of sync_every launches.  After each chunk the state is copied to a pinned slot; the
-  // host looks at a slot only once its event has fired (hipEventQuery, never blocking) and keeps
-  // up to kSlots chunks queued, so the GPU never waits for the host.  Launches queued behind a
-  // fired stop are no-ops on the device (sticky flag), so running ahead is harmless.
-  constexpr int kSlots = 4;
-  int head = 0, tail = 0;  // slots [tail, head) are in flight
+  // Chunks of sync_every launches.  The finalising workgroup of every step stores
+  // {steps_done, stopped} into pinned host memory; the host reads those two words between
+  // chunks (no copy, no synchronisation) and never runs more than kAhead chunks in front of
+  // the device.  Launches queued behind a fired stop are no-ops on the device (sticky flag).
+  constexpr int kAhead = 4;
+  volatile int *hs = c->h_status;
   bool stopped = false;
+  int queued = 0;
   while (remaining > 0 && !stopped) {
-    if (head - tail == kSlots) {  // ring full: wait for the oldest
-      HIPCHK(c, hipEventSynchronize(c->evp[tail % kSlots]));
+    while (queued - hs[0] > kAhead * c->sync_every && !hs[1]) {
+      if (hipStreamQuery(c->stream) == hipSuccess) break;  // everything queued has run
     }
-    while (tail < head) {
-      const hipError_t q = hipEventQuery(c->evp[tail % kSlots]);
-      if (q == hipErrorNotReady) break;
-      if (q != hipSuccess) return fail(c, CVH_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
-      stopped = stopped || c->h_state[tail % kSlots].stopped != 0;
-      ++tail;
-    }
-    if (stopped) break;
+    if (hs[1]) { stopped = true; break; }
     const int chunk = (int)(remaining < c->sync_every ? remaining : c->sync_every);
     rc = enqueue_impl(c, chunk);
     if (rc != CVH_OK) return rc;
     remaining -= chunk;
-    HIPCHK(c, hipMemcpyAsync(&c->h_state[head % kSlots], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->evp[head % kSlots], c->stream));
-    ++head;
+    queued += chunk;
   }
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
@@ -746,7 +751,21 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   memset(&a, 0, sizeof(a));
   a.h = c->h; a.w = c->w; a.K2 = K * K; a.L = L;
   a.invK2 = 1.0 / (K * K); a.L4 = L / 4; a.fast = use_fast(c) ? 1 : 0;
-  cvh_pm_grid(c->h, c->w, &a.tiles_x, &a.tiles_y);
+  const bool pm_wave = c->pm_kernel == 1;
+  if (pm_wave) {
+    a.tiles_x = (c->w + cvh_pm_wave_cols() - 1) / cvh_pm_wave_cols();
+    int sr = c->pm_strip_rows;
+    if (sr <= 0) {  // ~3 waves per SIMD resident
+      int nstrips = (c->num_cus * 3) / ((a.tiles_x + 3) / 4);
+      if (nstrips < 1) nstrips = 1;
+      sr = (c->h + nstrips - 1) / nstrips;
+      sr = ((sr + 3) / 8) * 8;  // nearest multiple of the 8-row loop body; measured best: 8 / 8-16 / 24 rows at 512^2 / 1024^2 / 2048^2
+      if (sr < 8) sr = 8;
+    }
+    a.strip_rows = sr;
+  } else {
+    cvh_pm_grid(c->h, c->w, &a.tiles_x, &a.tiles_y);
+  }
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   if (trips > 0) {
     for (int k = 0; k < c->C; ++k) {
@@ -754,7 +773,8 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
       int cur = 0;
       for (int t = 0; t < trips; ++t) {
         a.in = c->d_pm[cur]; a.out = c->d_pm[cur ^ 1];
-        HIPCHK(c, cvh_launch_pm_step(a, c->stream));
+        if (pm_wave) HIPCHK(c, cvh_launch_pm_wave(a, c->stream));
+        else HIPCHK(c, cvh_launch_pm_step(a, c->stream));
         cur ^= 1;
       }
       HIPCHK(c, cvh_launch_pm_store(c->d_pm[cur], c->d_img[k], c->n, c->stream));

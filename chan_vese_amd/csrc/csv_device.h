@@ -165,6 +165,10 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
       st->norm = nrm;
       st->steps_done = t + 1;
       if (nrm <= st->stop_cond) st->stopped = 1;  // src/main.cpp:1000, after the update
+      if (a.host_status) {  // the host polls these two words in pinned memory instead of copying the state back
+        __hip_atomic_store(&a.host_status[1], st->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     for (int k = 0; k < C; ++k) {
       st->c1[k] = sfin[2 + k] / sfin[0];          // nom / denom, src/main.cpp:280

@@ -83,6 +83,14 @@ __device__ __forceinline__ double heaviside_fast(double x, const double *tab /*L
   return 0.5 + __builtin_copysign(atpi, x);
 }
 
+// An "s" asm operand must really live in SGPRs: pin a wave-uniform pointer there.
+__device__ __forceinline__ const double *uniform_ptr(const double *p)
+{
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const double *)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double dpp_from_left(double v)
 {
   const long long vb = __double_as_longlong(v);
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         // slack area (compiler-visible, exact counted waits) is 4-5 us slower per launch.
         // hipcc pads no hazards inside asm: `ob` may have been written by the SALU instruction
         // just before (5 wait states before a VMEM read on gfx9), hence the s_nop 4.
-        const double *ob = live ? a.u_out + (size_t)i * w : a.dummy;
+        const double *ob = uniform_ptr(live ? a.u_out + (size_t)i * w : a.dummy);
         unsigned long long exec_keep;  // early-clobber OUTPUT: written before the inputs are read
         asm volatile("s_mov_b64 %0, exec\n\t"
                      "s_mov_b64 exec, %4\n\t"

@@ -55,6 +55,7 @@ struct CvhStepArgs {
   const double *atan2_tab;       // [CVH_ATAN2_N]: (pi/4 + atan((j-128)/128)) / pi
   int wave_minw;                 // waves per SIMD the wave kernel is compiled for (5..8)
   unsigned long long *dbg_times; // diagnostic: per-wave {start, end, hw id} stamps (100 MHz), or null
+  int *host_status;              // pinned host memory {steps_done, stopped}: written by the finaliser, polled by the host
   double *dummy;                 // >= max(w, 64) doubles that nobody reads: target of masked-off lanes' stores
   int wave_imgv;                 // wave kernel: 16-byte image pieces through LDS (w % 16 == 0)
   int wave_depth;                // wave kernel: rows of u kept in flight per lane (4 or 8)
@@ -75,6 +76,7 @@ struct CvhPmArgs {
   double L;
   double invK2, L4;  // FAST flavour: 1/K^2, L/4
   int fast;
+  int strip_rows;    // wave kernel: rows per wave
 };
 
 // ---- launchers (csv_kernels.hip / pm_kernels.hip / misc_kernels.hip) ----
@@ -92,6 +94,8 @@ int cvh_init_sum_blocks(int h, int w);
 
 hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hipStream_t s);
 hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s);
+hipError_t cvh_launch_pm_wave(const CvhPmArgs &a, hipStream_t s);
+int cvh_pm_wave_cols();
 hipError_t cvh_launch_pm_store(const double *state, uint8_t *plane, size_t n, hipStream_t s);
 void cvh_pm_grid(int h, int w, int *tiles_x, int *tiles_y);
 

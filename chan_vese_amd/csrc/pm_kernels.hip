@@ -53,48 +53,210 @@ __global__ __launch_bounds__(CVH_BLOCK) void pm_step_kernel(const CvhPmArgs a)
   }
   __syncthreads();
 
-  // g on rows i0-1 .. i0+PTH, cols j0-1 .. j0+PTW (:513-522)
-#pragma unroll 3
-  for (int idx = tid; idx < (PTH + 2) * GP; idx += CVH_BLOCK) {
-    const int r = idx / GP, c = idx - r * GP;
-    const int gi = i0 - 1 + r, gj = j0 - 1 + c;
-    double g = 1.0;  // image border ring (and anything clamped onto it)
-    if (gi > 0 && gi < h - 1 && gj > 0 && gj < w - 1) {
-      const double *p = &sI[(r + 1) * IP + (c + 1)];
-      // cv::Sobel ksize 3: row pass then column pass (see oracle/cv_oracle.c)
-      const double rm = p[-IP + 1] - p[-IP - 1], r0 = p[1] - p[-1], rp = p[IP + 1] - p[IP - 1];
-      const double gx = rm + r0 * 2 + rp;
-      const double sm = p[-IP - 1] + p[-IP] * 2 + p[-IP + 1];
-      const double sp = p[IP - 1] + p[IP] * 2 + p[IP + 1];
-      const double gy = sp - sm;
-      if (FAST) g = rcp_refined(__builtin_fma(__builtin_fma(gx, gx, gy * gy), a.invK2, 1.0));
-      else g = 1.0 / (1.0 + (gx * gx + gy * gy) / a.K2);
+  // g on rows i0-1 .. i0+PTH, cols j0-1 .. j0+PTW (:513-522).  Each lane marches down one
+  // column keeping the 3x3 window of I in registers (3 LDS reads per cell instead of 8); the
+  // two extra columns are done cell-per-lane by the wave that has the fewest rows.
+  const int tx = tid & 63, ty = tid >> 6;
+  auto g_of = [&](double a00, double a01, double a02, double a10, double a12, double a20, double a21, double a22,
+                  int gi, int gj) -> double {
+    // cv::Sobel ksize 3: row pass then column pass (see oracle/cv_oracle.c)
+    const double rm = a02 - a00, r0 = a12 - a10, rp = a22 - a20;
+    const double gx = rm + r0 * 2 + rp;
+    const double sm = a00 + a01 * 2 + a02;
+    const double sp = a20 + a21 * 2 + a22;
+    const double gy = sp - sm;
+    double g;
+    if (FAST) g = rcp_refined(__builtin_fma(__builtin_fma(gx, gx, gy * gy), a.invK2, 1.0));
+    else g = 1.0 / (1.0 + (gx * gx + gy * gy) / a.K2);
+    // image border ring (and anything clamped onto it) keeps g = 1
+    return (gi > 0 && gi < h - 1 && gj > 0 && gj < w - 1) ? g : 1.0;
+  };
+  {
+    constexpr int GR = PTH + 2;                 // g rows
+    constexpr int RPW = (GR + 3) / 4;           // rows per wave (9, 9, 9, 7 for PTH = 32)
+    const int r_lo = ty * RPW, r_hi = (r_lo + RPW) < GR ? (r_lo + RPW) : GR;
+    // g cell (r, c) sits at I-tile (r+1, c+1); window rows r, r+1, r+2, cols c, c+1, c+2
+    const double *p = &sI[r_lo * IP + tx];
+    double a00 = p[0], a01 = p[1], a02 = p[2];
+    double a10 = p[IP], a11 = p[IP + 1], a12 = p[IP + 2];
+    (void)a11;
+    for (int r = r_lo; r < r_hi; ++r) {
+      const double *pn = &sI[(r + 2) * IP + tx];
+      const double a20 = pn[0], a21 = pn[1], a22 = pn[2];
+      sg[r * GP + tx] = g_of(a00, a01, a02, a10, a12, a20, a21, a22, i0 - 1 + r, j0 - 1 + tx);
+      a00 = a10; a01 = a11; a02 = a12; a10 = a20; a11 = a21; a12 = a22;
     }
-    sg[idx] = g;
+    if (ty == 3) {                               // columns 64, 65: (PTH+2) x 2 cells, one per lane
+      for (int cell = tx; cell < GR * 2; cell += 64) {
+        const int r = cell >> 1, c = 64 + (cell & 1);
+        const double *q = &sI[r * IP + c];
+        sg[r * GP + c] = g_of(q[0], q[1], q[2], q[IP], q[IP + 2], q[2 * IP], q[2 * IP + 1], q[2 * IP + 2],
+                              i0 - 1 + r, j0 - 1 + c);
+      }
+    }
   }
   __syncthreads();
 
-  const int tx = tid & 63, ty = tid >> 6;
+  // update: lane tx owns column tx, wave ty rows ty*8 .. ty*8+7, marching down with the
+  // vertical neighbours of I and g in registers (:524-548)
   const int gj = j0 + tx;
+  {
+    constexpr int RPW = PTH / 4;
+    const int rb = ty * RPW;
+    const double *pI = &sI[(rb + 2) * IP + (tx + 2)];
+    const double *pg = &sg[(rb + 1) * GP + (tx + 1)];
+    double In = pI[-IP], I0 = pI[0];             // rows rb-1, rb
+    double cn = pg[-GP], c0 = pg[0];
 #pragma unroll
-  for (int q = 0; q < PTH / 4; ++q) {
-    const int r = ty * (PTH / 4) + q;
-    const int gi = i0 + r;
-    if (gi < h && gj < w) {
-      const double *p = &sI[(r + 2) * IP + (tx + 2)];
-      const double *g = &sg[(r + 1) * GP + (tx + 1)];
-      const double I0 = p[0], c0 = g[0];
+    for (int q = 0; q < RPW; ++q) {
+      const int gi = i0 + rb + q;
+      const double Is = pI[(q + 1) * IP], cs = pg[(q + 1) * GP];
+      const double Ie = pI[q * IP + 1], Iw = pI[q * IP - 1];
+      const double ce = pg[q * GP + 1], cw = pg[q * GP - 1];
+      double outv;
       if (FAST) {
-        double s = (g[GP] + c0) * (p[IP] - I0);
-        s = __builtin_fma(g[1] + c0, p[1] - I0, s);
-        s = __builtin_fma(g[-GP] + c0, p[-IP] - I0, s);
-        s = __builtin_fma(g[-1] + c0, p[-1] - I0, s);
-        a.out[(size_t)gi * w + gj] = __builtin_fma(a.L4, s, I0);
+        double s = (cs + c0) * (Is - I0);
+        s = __builtin_fma(ce + c0, Ie - I0, s);
+        s = __builtin_fma(cn + c0, In - I0, s);
+        s = __builtin_fma(cw + c0, Iw - I0, s);
+        outv = __builtin_fma(a.L4, s, I0);
       } else {
-        const double s = (g[GP] + c0) * (p[IP] - I0) + (g[1] + c0) * (p[1] - I0) +
-                         (g[-GP] + c0) * (p[-IP] - I0) + (g[-1] + c0) * (p[-1] - I0);
-        a.out[(size_t)gi * w + gj] = I0 + a.L * s / 4;  // :544-547
+        const double s = (cs + c0) * (Is - I0) + (ce + c0) * (Ie - I0) + (cn + c0) * (In - I0) + (cw + c0) * (Iw - I0);
+        outv = I0 + a.L * s / 4;  // :544-547
       }
+      if (gi < h && gj < w) a.out[(size_t)gi * w + gj] = outv;
+      In = I0; I0 = Is; cn = c0; c0 = cs;
+    }
+  }
+}
+
+// ---- wave-streaming variant (same arithmetic, no workgroup barriers) -----------------------
+// Each WAVE owns 60 output columns (lanes 0,1 and 62,63 are halo columns: the flux needs g one
+// column out, g needs I one column further) and marches down `strip_rows` rows.  The lane's own
+// column of I lives in a register ring of 8 rows (4 live + 4 in flight), x-neighbours of I and of
+// g go through per-wave LDS row slots written one step ahead of their use, g(i-1..i+1) of the own
+// column stay in registers.  Halo lanes compute like the others; only their stores are masked.
+constexpr int PWC = 60;
+
+// An "s" asm operand must really live in SGPRs: pin a wave-uniform pointer there.
+__device__ __forceinline__ const double *uniform_ptr(const double *p)
+{
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const double *)(((unsigned long long)hi << 32) | lo);
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(CVH_BLOCK) void pm_wave_kernel(const CvhPmArgs a)
+{
+  __shared__ double sx[4][8 * 64];   // per wave: 4 row slots of I + 4 row slots of g
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = a.h, w = a.w;
+  const int nwc = a.tiles_x, nbc = (nwc + 3) >> 2;
+  const int wc = (blockIdx.x % nbc) * 4 + wave, ws = blockIdx.x / nbc;
+  const int s0 = ws * a.strip_rows;
+  if (wc >= nwc || s0 >= h) return;
+  const int s1 = (s0 + a.strip_rows) < h ? (s0 + a.strip_rows) : h;
+  const int col = PWC * wc - 2 + lane;
+  const int colc = clampi(col, 0, w - 1);
+  const bool colborder = (colc == 0) || (colc == w - 1);
+  const bool lane_out = lane >= 2 && lane < 62 && col < w;
+  const unsigned long long store_mask = __ballot(lane_out);
+  const unsigned ooff32 = (unsigned)colc * 8u;
+  double *sI = sx[wave], *sG = sx[wave] + 4 * 64;
+  // neighbour addresses (halo lanes 0 / 63 read their own entry: their results are never used)
+  const int lw = lane > 0 ? lane - 1 : 0, le = lane < 63 ? lane + 1 : 63;
+
+  auto LD = [&](int r) -> double { const double *rp = a.in + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
+  auto fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto g_of = [&](double a00, double a01, double a02, double a10, double a12, double a20, double a21, double a22,
+                  int gi) -> double {
+    const double rm = a02 - a00, r0 = a12 - a10, rp = a22 - a20;
+    const double gx = rm + r0 * 2 + rp;
+    const double sm = a00 + a01 * 2 + a02;
+    const double sp = a20 + a21 * 2 + a22;
+    const double gy = sp - sm;
+    double g;
+    if (FAST) g = rcp_refined(__builtin_fma(__builtin_fma(gx, gx, gy * gy), a.invK2, 1.0));
+    else g = 1.0 / (1.0 + (gx * gx + gy * gy) / a.K2);
+    return (colborder || gi <= 0 || gi >= h - 1) ? 1.0 : g;   // :518-519 (clamped rows/cols sit on the ring)
+  };
+
+  // ---- prologue.  Ring q[j & 7] holds row s0-2+j of the own column for j = 0..7.
+  double q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = LD(s0 - 2 + j);
+  // neighbour rings: nw/ne[j & 3] = I(row s0-2+j, col -/+ 1); filled for j = 0..3
+  double nw[4], ne[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sI[j * 64 + lane] = q[j];
+  fence();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { nw[j] = sI[j * 64 + lw]; ne[j] = sI[j * 64 + le]; }
+  // g ring: gr[j & 3] = g(row s0-2+j); rows s0-1 (j=1) and s0 (j=2) are needed before step 0
+  double gr[4];
+  gr[1] = g_of(nw[0], q[0], ne[0], nw[1], ne[1], nw[2], q[2], ne[2], s0 - 1);
+  gr[2] = g_of(nw[1], q[1], ne[1], nw[2], ne[2], nw[3], q[3], ne[3], s0);
+  gr[0] = 1.0; gr[3] = 1.0;
+  fence();
+  // row s0-2 has served its purpose: its slot (index 0) now takes row s0+2, needed by step 0
+  sI[0 * 64 + lane] = q[4];
+  q[0] = LD(s0 + 6);                       // ... and its register slot takes row s0+6 (ring = rows i-1 .. i+6)
+  sG[2 * 64 + lane] = gr[2];
+  fence();
+  nw[0] = sI[0 * 64 + lw]; ne[0] = sI[0 * 64 + le];
+  double gw = sG[2 * 64 + lw], ge = sG[2 * 64 + le];   // g(s0, col -/+ 1)
+
+  for (int ib = s0; ib < s1; ib += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = ib + k;                 // output row; ring index of row r is (r - s0 + 2) & 7
+      // slots: row i-1 -> (k+1)&7, i -> (k+2)&7, i+1 -> (k+3)&7, i+2 -> (k+4)&7, i+3 -> (k+5)&7
+      const double Im = q[(k + 1) & 7], I0 = q[(k + 2) & 7], Ip = q[(k + 3) & 7], Ipp = q[(k + 4) & 7];
+      // publish row i+3 of this column, fetch its neighbours (used from the next step on)
+      sI[((k + 1) & 3) * 64 + lane] = q[(k + 5) & 7];
+      // g(i+1): window rows i, i+1, i+2
+      const double gnew = g_of(nw[(k + 2) & 3], I0, ne[(k + 2) & 3], nw[(k + 3) & 3], ne[(k + 3) & 3],
+                               nw[(k + 0) & 3], Ipp, ne[(k + 0) & 3], i + 1);
+      sG[((k + 3) & 3) * 64 + lane] = gnew;
+      fence();
+      const double nw_n = sI[((k + 1) & 3) * 64 + lw], ne_n = sI[((k + 1) & 3) * 64 + le];
+      const double gw_n = sG[((k + 3) & 3) * 64 + lw], ge_n = sG[((k + 3) & 3) * 64 + le];
+      const double cn = gr[(k + 1) & 3], c0 = gr[(k + 2) & 3], cs = gnew;
+      const double Iw = nw[(k + 2) & 3], Ie = ne[(k + 2) & 3];
+      double outv;
+      if (FAST) {
+        double s = (cs + c0) * (Ip - I0);
+        s = __builtin_fma(ge + c0, Ie - I0, s);
+        s = __builtin_fma(cn + c0, Im - I0, s);
+        s = __builtin_fma(gw + c0, Iw - I0, s);
+        outv = __builtin_fma(a.L4, s, I0);
+      } else {
+        const double s = (cs + c0) * (Ip - I0) + (ge + c0) * (Ie - I0) + (cn + c0) * (Im - I0) + (gw + c0) * (Iw - I0);
+        outv = I0 + a.L * s / 4;  // :544-547
+      }
+      {
+        // masked store in assembly (see csv_wave_kernel.hip for why); rows past the strip end are dropped
+        const double *ob = uniform_ptr(a.out + (size_t)i * w);
+        unsigned long long exec_keep;
+        if (i < s1)
+          asm volatile("s_mov_b64 %0, exec\n\t"
+                       "s_mov_b64 exec, %4\n\t"
+                       "s_nop 4\n\t"
+                       "global_store_dwordx2 %1, %2, %3\n\t"
+                       "s_mov_b64 exec, %0"
+                       : "=&s"(exec_keep) : "v"(ooff32), "v"(outv), "s"(ob), "s"(store_mask) : "memory");
+      }
+      // rotate: row i-1 is dead -> its slot takes row i+7; neighbour / g rings advance
+      q[(k + 1) & 7] = LD(i + 7);
+      nw[(k + 1) & 3] = nw_n; ne[(k + 1) & 3] = ne_n;   // row i+3
+      gr[(k + 3) & 3] = gnew;                            // row i+1
+      gw = gw_n; ge = ge_n;                              // g(i+1, col -/+ 1) for the next step
     }
   }
 }
@@ -132,6 +294,16 @@ hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hip
   hipLaunchKernelGGL(pm_load_kernel, dim3(flat_grid(n)), dim3(256), 0, s, plane, state, n);
   return hipGetLastError();
 }
+
+hipError_t cvh_launch_pm_wave(const CvhPmArgs &a, hipStream_t s)
+{
+  const int nbc = (a.tiles_x + 3) / 4, nstr = (a.h + a.strip_rows - 1) / a.strip_rows;
+  if (a.fast) hipLaunchKernelGGL(pm_wave_kernel<true>, dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  else hipLaunchKernelGGL(pm_wave_kernel<false>, dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+
+int cvh_pm_wave_cols() { return PWC; }
 
 hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s)
 {
