@@ -36,6 +36,9 @@ struct cvh_context {
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_depth = 4;
   double *d_dummy = nullptr;
+  int wave_skew = 0;            // per-mille: older workgroups get longer strips (see upload_strip_bounds)
+  int *d_bounds = nullptr;      // wave kernel: first row of every strip, [tiles_y + 1]
+  int bounds_key[4] = {-1, -1, -1, -1};
   int *h_status = nullptr;  // pinned + mapped: {steps_done, stopped} written by the device
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
@@ -127,6 +130,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_atan) (void)hipFree(c->d_atan);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
+  if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->h_status) (void)hipHostFree(c->h_status);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -174,6 +178,7 @@ static int create_impl(cvh_context *c)
   c->partial_rows = step_blocks > init_blocks ? step_blocks : init_blocks;
   HIPCHK(c, hipMalloc((void **)&c->d_partials, (size_t)c->partial_rows * cvh_nsums(c->C) * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_dummy, (size_t)(c->w > 64 ? c->w : 64) * sizeof(double)));
+  HIPCHK(c, hipMalloc((void **)&c->d_bounds, (size_t)(c->h + 2) * sizeof(int)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_status, 64, hipHostMallocMapped));
   c->h_status[0] = 0; c->h_status[1] = 0;
   HIPCHK(c, hipEventCreate(&c->ev0));
@@ -255,6 +260,9 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
       HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
       HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
     }
+  } else if (!strcmp(key, "wave_skew")) {
+    if (value < 0 || value > 500) return fail(c, CVH_ERR_ARG, "wave_skew must be 0..500 (per mille)");
+    c->wave_skew = (int)value;
   } else if (!strcmp(key, "wave_depth")) {
     if (value != 4 && value != 8) return fail(c, CVH_ERR_ARG, "wave_depth must be 4 or 8");
     c->wave_depth = (int)value;
@@ -263,7 +271,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "wave_sync")) {
     c->wave_sync = value != 0;
   } else if (!strcmp(key, "wave_prio")) {
-    c->wave_prio = value != 0;
+    if (value < 0 || value > 4) return fail(c, CVH_ERR_ARG, "wave_prio must be 0..4");
+    c->wave_prio = (int)value;
   } else if (!strcmp(key, "wave_lds_cap")) {
     c->wave_lds_cap = value != 0;
   } else if (!strcmp(key, "strip_rows")) {
@@ -425,9 +434,10 @@ static Geometry resolve_geometry(const cvh_context *c)
 {
   Geometry g;
   g.strip = c->kernel == 1;
-  // default: the wave kernel (any width; fastest measured); it addresses stores with 32-bit byte
-  // offsets from the buffer start, so images of 2^29 pixels or more use the tile kernel
-  if ((c->kernel == 2 || c->kernel == -1) && c->n < ((size_t)1 << 29) - 64) {
+  // default: the wave kernel (any width; fastest measured); it addresses the level set through
+  // buffer instructions with 32-bit byte offsets and marks dropped lanes with offset 2^31, so
+  // images of 2^28 pixels (2 GiB of level set) or more use the tile kernel
+  if ((c->kernel == 2 || c->kernel == -1) && c->n < ((size_t)1 << 28)) {
     // wave kernel: 63 output columns per wave, strip_rows rows per wave, 4 waves per workgroup;
     // one round of resident waves (wave_minw per SIMD)
     g.strip = 2;
@@ -501,14 +511,21 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->wave_depth = c->wave_depth;
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;
+  a->strip_bounds = c->d_bounds;
   a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
   a->inv_eps = 1.0 / c->p.eps;
   a->dk1 = pi / c->p.eps;
   a->dk2 = pi * c->p.eps;
+  {
+    const double e = c->p.eps, e2 = e * e;
+    a->far_k[0] = e / pi; a->far_k[1] = -(e * e2) / (3.0 * pi);
+    a->far_k[2] = (e * e2 * e2) / (5.0 * pi); a->far_k[3] = -(e * e2 * e2 * e2) / (7.0 * pi);
+    a->far_thr = 64.0 * e;
+  }
   a->npix = (double)c->n;
   for (int k = 0; k < CVH_MAX_CHANNELS; ++k) a->sum_img[k] = c->sum_img[k];
-  a->derive_complement = use_fast(c) ? 1 : 0;
+  a->derive_complement = use_fast(c) ? (g.strip == 2 ? 2 : 1) : 0;  // 2: the wave kernel sums H - 1/2
   a->use_lut = c->use_lut;
   a->use_dma = c->use_dma;
 }
@@ -552,8 +569,37 @@ static int prepare(cvh_context *c)
   return CVH_OK;
 }
 
+// Wave kernel: rows [bounds[k], bounds[k+1]) belong to strip k.  All waves start together, but at
+// equal priority the SIMD arbiter favours the OLDEST wave, i.e. the lowest workgroup index, and
+// equal strips then finish up to 10 us apart inside one SIMD (tools/wave_timeline.py) -- the tail
+// runs at 1-2 waves per SIMD.  wave_skew = 1000 alpha makes the strip length fall linearly from
+// (1 + alpha) to (1 - alpha) times the mean with the strip index, so they finish together.
+static int upload_strip_bounds(cvh_context *c, const Geometry &g)
+{
+  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew, c->h};
+  if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
+  const int S = g.tiles_y;
+  std::vector<int> b((size_t)S + 1);
+  const double alpha = c->wave_skew / 1000.0;
+  for (int k = 0; k <= S; ++k) {
+    long v;
+    if (c->wave_skew == 0) v = (long)k * g.strip_rows;
+    else { const double x = (double)k / S; v = (long)((double)c->h * (x + alpha * x * (1.0 - x))); }
+    b[k] = (int)(v < c->h ? v : c->h);
+  }
+  b[S] = c->h;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
+  HIPCHK(c, hipMemcpy(c->d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+  memcpy(c->bounds_key, key, sizeof(key));
+  return CVH_OK;
+}
+
 static int enqueue_impl(cvh_context *c, int nsteps)
 {
+  {
+    const Geometry g = resolve_geometry(c);
+    if (g.strip == 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
+  }
   for (int s = 0; s < nsteps; ++s) {
     CvhStepArgs a;
     fill_args(c, &a, (c->cur_base + c->enqueued) & 1);

@@ -150,7 +150,12 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
   if (tid == 0) {
     CvhState *st = a.st;
     if (a.derive_complement && !is_init) {
-      // FAST flavour carries only sum H and sum I H; complements from exact totals
+      // FAST flavour carries only sum H and sum I H; complements from exact totals.
+      // derive_complement == 2 (wave kernel): the sums are of H - 1/2.
+      if (a.derive_complement == 2) {
+        sfin[0] += 0.5 * a.npix;
+        for (int k = 0; k < C; ++k) sfin[2 + k] += 0.5 * a.sum_img[k];
+      }
       sfin[1] = a.npix - sfin[0];
       for (int k = 0; k < C; ++k) sfin[2 + C + k] = a.sum_img[k] - sfin[2 + k];
     }

@@ -38,8 +38,8 @@ struct WaveSmem {
   static constexpr int off_red = off_x + 4 * wave_doubles;                 // 4*NS
   static constexpr int off_fin = off_red + 4 * NS + (4 * NS) % 2;          // NS
   static constexpr int off_atan = off_fin + NS + NS % 2;                   // FAST: CVH_ATAN2_N
-  static constexpr int off_lut = off_atan + (FAST ? CVH_ATAN2_N + 1 : 0);  // LUT: C*256
-  static constexpr int off_flag = off_lut + (LUT ? C * 256 : 0);
+  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // LUT: C*256 x {term, I}, 16-byte aligned
+  static constexpr int off_flag = off_lut + (LUT ? C * 512 : 0);
   static constexpr int doubles = off_flag + 2;
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
@@ -49,23 +49,39 @@ struct WaveSmem {
 // atan(a) = pi/4 + atan((a-1)/(a+1)); with y ~ (a-1)/(a+1) rounded to c = j/128,
 // atan(y) = atan(c) + atan(z), z = (n - c d)/(d + c n), n = a-1, d = a+1: ONE accurate
 // reciprocal (of d + c n) and one raw one (to pick c).  |z| <= 1/256.
-__device__ __forceinline__ double heaviside_fast(double x, const double *tab /*LDS, CVH_ATAN2_N*/)
+// d = a*b + c as a 3-address v_fma_f64: with a constant addend hipcc otherwise copies the
+// constant into the destination first (v_mov_b64 + v_fmac_f64), one extra VALU slot per use.
+__device__ __forceinline__ double fma3(double a, double b, double c)
 {
-  const double a = fmin(fabs(x), 1e300);
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// Coefficients of the far-field series with eps and 1/pi folded in (wave-uniform).
+struct FarCoef { double k0, k1, k2, k3, thr; };
+
+// H_eps(u) - 1/2 = copysign(atan(|u|/eps)/pi, u).  The sums carry this CENTRED value (the
+// finalisation adds N/2 and sum(I)/2, exact integers or half-integers): one addition less per pixel.
+__device__ __forceinline__ double heaviside_centred_fast(double u, double inv_eps, const FarCoef &fc,
+                                                         const double *tab /*LDS, CVH_ATAN2_N*/)
+{
   // Far field, decided per WAVE (uniform branch): with the reference's default time step the
-  // level set sits at |u| >> 64 everywhere after a handful of iterations.  There
-  // atan(a) = pi/2 - atan(1/a) and the series of atan(t), t <= 1/64, truncated after t^7/7
-  // (next term < 7e-18) needs one reciprocal and no table.
-  if (__builtin_amdgcn_ballot_w64(a < 64.0) == 0ull) {
-    const double r0 = __builtin_amdgcn_rcp(a);
-    const double t = __builtin_fma(__builtin_fma(-a, r0, 1.0), r0, r0);
-    const double t2 = t * t;
-    double p = __builtin_fma(t2, -1.0 / 7.0, 0.2);
-    p = __builtin_fma(p, t2, -1.0 / 3.0);
-    const double s = __builtin_fma(t * t2, p, t);                    // atan(1/a)
-    const double atpi = __builtin_fma(-s, 1.0 / kPi, 0.5);           // (pi/2 - s)/pi
-    return 0.5 + __builtin_copysign(atpi, x);
+  // level set sits at |u| >> 64 eps everywhere after a handful of iterations.  There
+  // atan(a) = pi/2 - atan(1/a), a = |u|/eps, and the series of atan(t), t = eps/|u| <= 1/64,
+  // truncated after t^7/7 (next term < 7e-18) needs one reciprocal and no table.  In terms of
+  // r = 1/u (signed): atan(eps r)/pi = r (k0 + r^2 (k1 + r^2 (k2 + r^2 k3))), k_i = (-1)^i eps^(2i+1)/((2i+1) pi).
+  if (__builtin_amdgcn_ballot_w64(fabs(u) < fc.thr) == 0ull) {
+    const double r0 = __builtin_amdgcn_rcp(u);
+    const double r = __builtin_fma(__builtin_fma(-u, r0, 1.0), r0, r0);
+    const double r2 = r * r;
+    double p = fma3(r2, fc.k3, fc.k2);
+    p = fma3(p, r2, fc.k1);
+    p = fma3(p, r2, fc.k0);
+    return __builtin_fma(-r, p, __builtin_copysign(0.5, u));
   }
+  const double x = u * inv_eps;
+  const double a = fmin(fabs(x), 1e300);
   const double n = a - 1.0, d = a + 1.0;
   const double y0 = n * __builtin_amdgcn_rcp(d);
   const double fi = __builtin_rint(y0 * 128.0);
@@ -77,18 +93,45 @@ __device__ __forceinline__ double heaviside_fast(double x, const double *tab /*L
   const double r = __builtin_fma(__builtin_fma(-den, r0, 1.0), r0, r0);
   const double z = num * r;
   const double z2 = z * z;
-  const double p = __builtin_fma(z2, 0.2, -1.0 / 3.0);
+  const double p = fma3(z2, 0.2, -1.0 / 3.0);
   const double az = __builtin_fma(z * z2, p, z);
   const double atpi = __builtin_fma(az, 1.0 / kPi, tab[j + 128]);  // atan(a)/pi in [0, 1/2]
-  return 0.5 + __builtin_copysign(atpi, x);
+  return __builtin_copysign(atpi, x);
 }
 
-// An "s" asm operand must really live in SGPRs: pin a wave-uniform pointer there.
-__device__ __forceinline__ const double *uniform_ptr(const double *p)
+// FAST form of d+ / sqrt(d+^2 + d0^2 + eta^2) (src/main.cpp:365-368) from the three samples
+// along one axis: evaluated as 2d+ / sqrt((2d+)^2 + (2d0)^2 + 4 eta^2) -- the same value bit for
+// bit (every intermediate is an exact power-of-two multiple), one instruction shorter because
+// 2 d0 = fwd - bwd needs no halving and 2 u(0) is shared by both axes.
+__device__ __forceinline__ double normalised4(double fwd, double bwd, double centre2)
 {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const double *)(((unsigned long long)hi << 32) | lo);
+  const double a = __builtin_fma(fwd, 2.0, -centre2), d = fwd - bwd;
+  return a * rsqrt_refined(__builtin_fma(a, a, __builtin_fma(d, d, 4.0 * kEta2)));
+}
+
+// Level-set rows and image pieces move through BUFFER instructions: the row base is a scalar
+// offset (soffset), the lane's column a constant VGPR offset -- no per-row vector address
+// arithmetic -- and a lane whose offset lies outside the buffer (>= num_records) is dropped
+// by the hardware.  That gives a maskless, straight-line, compiler-visible store: hipcc counts
+// loads AND stores in its vmcnt waits, so the 4-row load pipeline and the stores stay in flight.
+// (An `if (lane_valid)` store is a control-flow diamond; a store hidden in inline assembly is not
+// counted, and every counted wait then also drains the stores and the younger loads: measured,
+// waves spent 50 % of their cycles in s_waitcnt -- profiles/README.md.)
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;   // beyond any buffer this kernel accepts (< 2 GiB)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000 /* raw, 32-bit data format (gfx950) */);
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f64(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
 }
 
 __device__ __forceinline__ double dpp_from_left(double v)
@@ -98,6 +141,10 @@ __device__ __forceinline__ double dpp_from_left(double v)
   const int hi = __builtin_amdgcn_mov_dpp((int)(vb >> 32), 0x138, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+
+#ifndef CVH_STORE_MOD
+#define CVH_STORE_MOD ""
+#endif
 
 template <int C, bool FAST, bool LUT, int MINW, bool IMGV, int G>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStepArgs a)
@@ -125,6 +172,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   for (int k = 0; k < C; ++k) { c1[k] = a.st->c1[k]; c2[k] = a.st->c2[k]; l1[k] = a.lambda1[k]; l2[k] = a.lambda2[k]; }
   const double eps = a.eps;
   const double eps2 = eps * eps;
+  const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_thr};
 
   // the tables are filled while the first rows are in flight: see fill_tables() below
   auto fill_tables = [&]() {
@@ -137,7 +185,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         const double v = (double)tid;
         const double d1 = v - c1[k], d2 = v - c2[k];
         const double reg = (d2 * d2) * l2[k] - (d1 * d1) * l1[k];
-        slut[k * 256 + tid] = (k == 0) ? __builtin_fma(reg, a.beta, a.gamma) : reg * a.beta;
+        slut[2 * (k * 256 + tid)] = (k == 0) ? __builtin_fma(reg, a.beta, a.gamma) : reg * a.beta;
+        slut[2 * (k * 256 + tid) + 1] = v;   // the sample as a double rides along (saves the conversion)
       }
     }
   };
@@ -150,12 +199,12 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   const int nwc = a.tiles_x;           // wave-columns per image row
   const int nbc = (nwc + 3) >> 2;      // workgroups per strip
   const int wc = (blockIdx.x % nbc) * 4 + wave, ws = blockIdx.x / nbc;
-  const int s0 = ws * a.strip_rows;
+  const int s0 = a.strip_bounds[ws];
   const bool active = wc < nwc;        // the last workgroup of a strip may hold idle waves
   const int col = WCOLS * wc - 1 + lane;                // lane 0 = left halo column
   const bool lane_valid = active && (lane >= 1) && (col < w);
   if (active) {
-    const int s1 = (s0 + a.strip_rows) < h ? (s0 + a.strip_rows) : h;
+    const int s1 = a.strip_bounds[ws + 1];
     const int colc = clampi(col, 0, w - 1);
     const double fx = (col <= 0) ? 0.0 : 1.0;           // kappa_x(i,0) = 0 (:371)
     // Every vector-memory operation below is issued by ALL lanes on EVERY row (halo / out-of-
@@ -168,16 +217,22 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     double *x_own = xs + 1 + lane;
     double *x_ext = xlane ? xs + xrow * XPITCH + (xside ? 65 : 0) : xs + XSLOTS * XPITCH + lane;  // lanes >= 8: scratch
     const double *x_w = xs + lane, *x_e = xs + lane + 2;
-    const unsigned ooff32 = (unsigned)colc * 8u;                  // byte offset of this lane's column in a row
-    const unsigned long long store_mask = __ballot(lane_valid);   // lanes that own an output pixel
+    const unsigned rowbytes = (unsigned)w * 8u, ubytes = (unsigned)h * rowbytes;   // < 2 GiB (launcher)
+    const unsigned voff_u = (unsigned)colc * 8u;                  // byte offset of this lane's column in a row
+    const unsigned voff_st = lane_valid ? voff_u : kOobOffset;    // lanes that own no output pixel store nowhere
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u_in, ubytes);
 
     // row base pointers are wave-uniform (scalar); the lane contributes a constant 32-bit offset
 #ifdef CVH_ABLATE_MEMORY   // diagnostic build: no global loads/stores in the loop (results are wrong)
     auto U = [&](int r) -> double { return (double)(r & 15) * 0.37 + (double)colc * 0.001; };
 #else
-    auto U = [&](int r) -> double { const double *rp = a.u_in + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
+    auto U = [&](int r) -> double { return buf_load_f64(ru, voff_u, (unsigned)clampi(r, 0, h - 1) * rowbytes); };
 #endif
-    auto UX = [&](int r0) -> double { return a.u_in[(size_t)clampi(r0 + xrow, 0, h - 1) * w + xcol]; };
+    const unsigned voff_x = ((unsigned)xrow * (unsigned)w + (unsigned)xcol) * 8u;
+    auto UX = [&](int r0) -> double {   // r0 >= 0; away from the bottom edge the lane's offset is a constant
+      if (r0 + 3 < h) return buf_load_f64(ru, voff_x, (unsigned)r0 * rowbytes);
+      return buf_load_f64(ru, ((unsigned)clampi(r0 + xrow, 0, h - 1) * (unsigned)w + (unsigned)xcol) * 8u, 0u);
+    };
     auto IM = [&](int k, int r) -> int { const uint8_t *rp = a.img[k] + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
 
     // ---- prologue
@@ -205,10 +260,15 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     const int ibyte = colc - icol0;                                // this lane's byte within a tile row (0..79)
     typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
     uint4_t iq[G][C];
+    const unsigned voff_i = (unsigned)(ilane ? irow : 0) * (unsigned)w + (unsigned)ipc;
     auto IMQ = [&](int g, int r0) {
 #pragma unroll
       for (int ch = 0; ch < C; ++ch)
-        iq[g][ch] = *reinterpret_cast<const uint4_t *>(a.img[ch] + (size_t)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * w + ipc);
+      {
+        const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[ch], (unsigned)h * (unsigned)w);
+        if (r0 + 3 < h) iq[g][ch] = __builtin_amdgcn_raw_buffer_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w, 0);
+        else iq[g][ch] = __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * (unsigned)w + (unsigned)ipc, 0u, 0);
+      }
     };
     auto IMTILE = [&](int g) {  // tile of the group whose pieces are in iq[g] -> im[][]
       if (ilane) {
@@ -256,7 +316,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double uw = x_w[0 * XPITCH], ue = x_e[0 * XPITCH];
-    double ny_prev = normalised<FAST>(u0 - um, central(um2, u0));  // ny at row s0-1
+    double ny_prev = FAST ? normalised4(u0, um2, um + um) : normalised<false>(u0 - um, central(um2, u0));  // ny at row s0-1
+    // kappa_y(0, .) = 0 (:372): on the image's first row ny_prev is set to that row's own ny,
+    // computed with the very expression the row uses, so ny - ny_prev is exactly 0 there
+    if (s0 == 0) ny_prev = FAST ? normalised4(q[0], um, u0 + u0) : normalised<false>(q[0] - u0, central(um, q[0]));
 
     // one row of the march; `live` (wave-uniform) is false only for rows past the strip end
     auto row = [&](int i, int g, int k, bool live) {
@@ -284,8 +347,9 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 #endif
       double nx, ny;
       if (FAST) {
-        nx = normalised<true>(ue - u0, 0.5 * (ue - uw));
-        ny = normalised<true>(up - u0, 0.5 * (up - um));
+        const double u02 = u0 + u0;
+        nx = normalised4(ue, uw, u02);
+        ny = normalised4(up, um, u02);
       } else {
         nx = normalised<false>(ue - u0, central(uw, ue));  // :365-366
         ny = normalised<false>(up - u0, central(um, up));  // :367-368
@@ -293,22 +357,30 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       const double nxl = dpp_from_left(nx);
       double kappa;
       if (FAST) {
-        kappa = __builtin_fma(nx - nxl, fx, (i == 0) ? 0.0 : ny - ny_prev);
+        kappa = __builtin_fma(nx - nxl, fx, ny - ny_prev);
       } else {
         const double kx = (col <= 0) ? 0.0 : nx - nxl;                // :371
-        const double ky = (i == 0) ? 0.0 : ny - ny_prev;              // :372
+        const double ky = ny - ny_prev;                               // :372 (row 0: see ny_prev above)
         kappa = kx + ky;                                              // :373
       }
       double Ik[C];
+      if (!(FAST && LUT)) {
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) Ik[ch] = (double)im[ch][k];
+        for (int ch = 0; ch < C; ++ch) Ik[ch] = (double)im[ch][k];
+      }
       double ud, hv;
       if (FAST) {
         double reg;
         if (LUT) {
-          reg = slut[im[0][k]];
+          typedef double double2_t __attribute__((ext_vector_type(2)));
+          const double2_t *lut2 = reinterpret_cast<const double2_t *>(slut);
+          const double2_t e0 = lut2[im[0][k]];
+          reg = e0.x; Ik[0] = e0.y;
 #pragma unroll
-          for (int ch = 1; ch < C; ++ch) reg += slut[ch * 256 + im[ch][k]];
+          for (int ch = 1; ch < C; ++ch) {
+            const double2_t e = lut2[ch * 256 + im[ch][k]];
+            reg += e.x; Ik[ch] = e.y;
+          }
         } else {
           reg = 0.0;
 #pragma unroll
@@ -336,25 +408,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         ud = ud * (eps / (kPi * (eps2 + u0 * u0)));      // :209, :992
       }
       const double un = u0 + ud;                         // :994
-      if (FAST) hv = heaviside_fast(un * a.inv_eps, satan);
+      if (FAST) hv = heaviside_centred_fast(un, a.inv_eps, fc, satan);   // H - 1/2: see finalize()
       else hv = heaviside_strict(un, eps);
-      {
-        // Valid lanes store the pixel (rows past the strip end go to the dummy row).  The store is
-        // written in assembly with the lane mask applied to EXEC by hand: an `if (lane_valid)`
-        // store becomes a control-flow diamond and hipcc then waits for (nearly) all outstanding
-        // loads at every join.  Measured alternatives (profiles/README.md): an all-lane store to a
-        // slack area (compiler-visible, exact counted waits) is 4-5 us slower per launch.
-        // hipcc pads no hazards inside asm: `ob` may have been written by the SALU instruction
-        // just before (5 wait states before a VMEM read on gfx9), hence the s_nop 4.
-        const double *ob = uniform_ptr(live ? a.u_out + (size_t)i * w : a.dummy);
-        unsigned long long exec_keep;  // early-clobber OUTPUT: written before the inputs are read
-        asm volatile("s_mov_b64 %0, exec\n\t"
-                     "s_mov_b64 exec, %4\n\t"
-                     "s_nop 4\n\t"
-                     "global_store_dwordx2 %1, %2, %3\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(exec_keep) : "v"(ooff32), "v"(un), "s"(ob), "s"(store_mask) : "memory");
-      }
+      // rows past the strip end (wave-uniform) get an empty buffer: every lane is out of range
+      buf_store_f64(un, make_rsrc(live ? a.u_out : a.dummy, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {  // halo / out-of-image lanes are zeroed once after the loop
         acc[0] += hv;
         if (!FAST) acc[1] += (1 - hv);
@@ -395,7 +452,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         // Equal-work waves drift apart under oldest-first issue arbitration and the tail then
         // runs at 1-2 waves per SIMD.  Waves that are AHEAD lower their priority (by quarter of
         // the strip), so laggards catch up and all waves finish together.
-        const int pq = ((s1 - ib) * 4 - 1) / (s1 - s0);  // 3,2,1,0 as the strip completes
+        const int rem = s1 - ib, len = s1 - s0;
+        int pq;
+        if (a.wave_prio == 1) pq = (rem * 4 - 1) / len;  // 3,2,1,0 by quarters of the strip
+        else {  // thresholds crowd towards the end: only the last level's length sets the finishing spread
+          const int sh = a.wave_prio == 4 ? 1 : a.wave_prio;  // 2: 1/4,1/8,1/16 of the strip left; 3: 1/2,1/4,1/8; 4: 1/8,1/16,1/32
+          pq = (rem << (4 - sh)) > len ? 3 : ((rem << (5 - sh)) > len ? 2 : ((rem << (6 - sh)) > len ? 1 : 0));
+        }
         if (pq != prio) {
           prio = pq;
           if (pq >= 3) __builtin_amdgcn_s_setprio(3);
@@ -423,7 +486,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     __syncthreads();
   }
   if (!active && a.wave_sync) {                // idle waves still meet the per-iteration barrier
-    const int s1i = (s0 + a.strip_rows) < h ? (s0 + a.strip_rows) : h;
+    const int s1i = a.strip_bounds[ws + 1];
     for (int ib = s0; ib < s1i; ib += 4) __builtin_amdgcn_s_barrier();
   }
 

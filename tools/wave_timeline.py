@@ -10,7 +10,7 @@ for kv in sys.argv[1:]:
     k, v = kv.split("="); ctx.set_option(k, int(v))
 ctx.set_option("debug_times", 1)
 ctx.set_image([synth.disk(n)]); ctx.set_levelset(capi.checkerboard_host(n, n))
-ctx.run(5)
+ctx.run(int(__import__('os').environ.get('ITERS', '5')))
 L = capi.lib()
 buf = np.zeros(2_000_000, dtype=np.uint64); words = C.c_long(0); nb = C.c_int(0)
 L.cvh_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int)]
@@ -36,4 +36,24 @@ hist, edges = np.histogram(en, bins=12)
 print("end-time histogram:", list(zip(np.round(edges[:-1], 1), hist)))
 late = st > 5
 print("waves starting later than 5 us:", late.sum())
+# where do the late waves live?
+okidx = np.nonzero(ok)[0]
+blk = okidx // 4; wv = okidx % 4
+nwc = (n + 62) // 63; nbc = (nwc + 3) // 4
+strip = blk // nbc; wcol = (blk % nbc) * 4 + wv
+def grp(name, keyv):
+    u_, inv = np.unique(keyv, return_inverse=True)
+    m = np.bincount(inv, weights=en) / np.bincount(inv)
+    print(name, "groups", len(u_), "mean end: min %.1f p50 %.1f max %.1f" % (m.min(), np.median(m), m.max()), "| first 8:", np.round(m[:8], 1), "last 4:", np.round(m[-4:], 1))
+grp("by xcc", xcc); grp("by CU", key); grp("by strip", strip); grp("by wave column", wcol)
+simd = (hw >> 4) & 3
+grp("by simd", simd)
+percu = np.bincount(np.unique(key, return_inverse=True)[1])
+u_, inv = np.unique(key, return_inverse=True)
+mcu = np.bincount(inv, weights=en) / np.bincount(inv)
+for c_ in sorted(set(percu)): print("CUs with", c_, "waves:", (percu == c_).sum(), "mean end %.1f" % mcu[percu == c_].mean())
+# spread inside a CU
+mx = np.zeros(len(u_)); mn = np.full(len(u_), 1e9)
+np.maximum.at(mx, inv, en); np.minimum.at(mn, inv, en)
+print("within-CU end spread: median %.1f max %.1f; CU last-end: min %.1f median %.1f max %.1f" % (np.median(mx - mn), (mx - mn).max(), mx.min(), np.median(mx), mx.max()))
 ctx.close()
