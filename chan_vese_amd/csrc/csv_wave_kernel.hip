@@ -20,6 +20,7 @@
 //     (kappa_x(.,0) = 0, kappa_y(0,.) = 0, src/main.cpp:371-372) is a 0/1 factor.
 // One partial row of sums per workgroup; finalisation as in the other variants.
 #include "csv_device.h"
+#include <type_traits>
 
 using namespace cvh_dev;
 
@@ -235,22 +236,17 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     };
     auto IM = [&](int k, int r) -> int { const uint8_t *rp = a.img[k] + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
 
-    // ---- prologue
-    // Rows of this lane's column live in a register ring.  G == 2: ring of 8, slot (t & 7) holds
-    // row s0+1+t at step t (`up`), `u0` and `um` are slots t-1 and t-2, and the slot of the row
-    // that has just died is refilled with the row 8 ahead: every loop-carried value keeps its
-    // register from one iteration to the next, so the loop back-edge needs no copies of
-    // in-flight loads (hipcc otherwise waits for them there and drains the pipeline every
-    // iteration).  G == 1 keeps the shifted um/u0/up form.
-    constexpr bool RING8 = (G == 2);
-    const double um2 = U(s0 - 2);
-    double um = U(s0 - 1), u0 = U(s0);
-    double q[4 * G];
+    // ---- data flow of the march (G = 1)
+    // Global loads never stay in flight across the loop back-edge.  Each iteration handles a GROUP of
+    // 4 rows ib..ib+3: at its start it requests the level-set rows, halo extras and image pieces of
+    // the NEXT group into temporaries; at its end it waits for them and parks them in this wave's LDS
+    // (4-slot row ring, image tile).  The rows themselves (own column and both neighbours) are read
+    // back from the ring, `um`/`u0` rotate through registers.  hipcc counts every vector-memory
+    // operation here in its vmcnt waits and nothing loop-carried is pending at the back-edge, where
+    // it would otherwise copy registers and wait for ALL outstanding loads (vmcnt(0)) -- the earlier
+    // register-ring form drained its pipeline once per group that way.
+    // Ring slot j holds row ib+1+j (66 doubles: west extra, 64 lanes, east extra).
     int im[C][4];
-    // Image samples.  IMGV (w % 16 == 0): the 64-byte row segments of 4 rows are fetched as
-    // 20 aligned 16-byte pieces by ONE load (lanes 0..19), staged in a per-wave LDS tile and
-    // read back as bytes: one vector-memory instruction per 4 rows instead of one 64 x 1-byte
-    // load per row (measured: the byte loads alone cost ~18 us of a 4096^2 launch).
     unsigned char *simg = reinterpret_cast<unsigned char *>(xs + XSLOTS * XPITCH + 64);
     const int icol0 = (WCOLS * wc - 1) & ~15;                      // 16-byte aligned start column (may be < 0)
     const int ipiece = lane % 5, irow = lane / 5;                  // lanes 0..19: piece of row irow
@@ -258,93 +254,86 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     int ipc = icol0 + 16 * ipiece;
     ipc = ipc < 0 ? 0 : (ipc > w - 16 ? w - 16 : ipc);             // clamped pieces only feed clamped columns
     const int ibyte = colc - icol0;                                // this lane's byte within a tile row (0..79)
-    typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-    uint4_t iq[G][C];
     const unsigned voff_i = (unsigned)(ilane ? irow : 0) * (unsigned)w + (unsigned)ipc;
-    auto IMQ = [&](int g, int r0) {
-#pragma unroll
-      for (int ch = 0; ch < C; ++ch)
-      {
-        const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[ch], (unsigned)h * (unsigned)w);
-        if (r0 + 3 < h) iq[g][ch] = __builtin_amdgcn_raw_buffer_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w, 0);
-        else iq[g][ch] = __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * (unsigned)w + (unsigned)ipc, 0u, 0);
-      }
+    // a piece clamped at the image edge lands where its columns are expected
+    unsigned char *ipiece_dst = simg + irow * IMGP + ((icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0);
+    // Image samples.  IMGV (w % 16 == 0): the 64-byte row segments of 4 rows are fetched as
+    // 20 aligned 16-byte pieces by ONE load (lanes 0..19), staged in a per-wave LDS tile and
+    // read back as bytes: one vector-memory instruction per 4 rows instead of one 64 x 1-byte
+    // load per row (measured: the byte loads alone cost ~18 us of a 4096^2 launch).
+    auto IMQ = [&](int ch, int r0) -> u32x4_t {
+      const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[ch], (unsigned)h * (unsigned)w);
+      if (r0 + 3 < h) return __builtin_amdgcn_raw_buffer_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w, 0);
+      return __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * (unsigned)w + (unsigned)ipc, 0u, 0);
     };
-    auto IMTILE = [&](int g) {  // tile of the group whose pieces are in iq[g] -> im[][]
-      if (ilane) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          // a piece clamped at the image edge lands where its columns are expected
-          const int dst = (icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0;
-          *reinterpret_cast<uint4_t *>(simg + (ch * 4 + irow) * IMGP + dst) = iq[g][ch];
-        }
-      }
+    auto lds_fence = [&]() {
+      // the ring is exchanged between LANES of this wave: LDS operations of one wave execute in
+      // order, the fences only stop the compiler from reordering them
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // parks the next group's data: rows T[j] -> slot j, extras, image pieces / bytes
+    auto park = [&](const double (&T)[4], double X, const u32x4_t (&IQ)[C], const int (&IB)[C][4]) {
+      lds_fence();                              // all reads of the current group are done
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x_own[j * XPITCH] = T[j];
+      *x_ext = X;
+      if (IMGV) {
+        if (ilane) {
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) *reinterpret_cast<u32x4_t *>(ipiece_dst + ch * 4 * IMGP) = IQ[ch];
+        }
+      }
+      lds_fence();
 #pragma unroll
       for (int ch = 0; ch < C; ++ch)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) im[ch][k] = simg[(ch * 4 + k) * IMGP + ibyte];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 4; ++k) im[ch][k] = IMGV ? (int)simg[(ch * 4 + k) * IMGP + ibyte] : IB[ch][k];
     };
-#pragma unroll
-    for (int k = 0; k < 4 * G; ++k) q[k] = U(s0 + 1 + k);
-    if (RING8) { q[6] = um; q[7] = u0; }       // slots of rows s0-1, s0 (rows s0+7, s0+8 are requested at steps 0, 1)
-    if (IMGV) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) IMQ(g, s0 + 4 * g);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, s0 + k);
-    }
-    double xq[G];
+
+    // ---- prologue: rows s0-2 .. s0 in registers, rows s0+1 .. s0+4 and the image rows s0 .. s0+3 in LDS
+    const double um2 = U(s0 - 2);
+    double um = U(s0 - 1), u0 = U(s0);
+    double uw, ue;
     {
-      const double x0 = UX(s0);
+      double T[4];
+      u32x4_t IQ[C];
+      int IB[C][4];
 #pragma unroll
-      for (int g = 1; g < G; ++g) xq[g] = UX(s0 + 4 * g);  // xq[g]: extras of rows base+4g .. (g >= 1)
-      xq[0] = UX(s0 + 4 * G);                               // xq[0]: extras of the next iteration's first group
+      for (int j = 0; j < 4; ++j) T[j] = U(s0 + 1 + j);
+      const double X0 = UX(s0);                 // extras of rows s0 .. s0+3: only row s0's are used
+      const double X = UX(s0 + 1);              // extras of rows s0+1 .. s0+4
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        if (IMGV) IQ[ch] = IMQ(ch, s0);
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) IB[ch][k] = IM(ch, s0 + k);
+        }
+      }
       fill_tables();                            // overlaps the prologue's loads
       __syncthreads();
-      *x_ext = x0;                              // extras of rows s0 .. s0+3 -> slots 0..3
+      // neighbours of row s0 through slot 0, before the ring takes rows s0+1 ..
+      x_own[0] = u0;
+      if (xrow == 0) *x_ext = X0;
+      lds_fence();
+      uw = x_w[0]; ue = x_e[0];
+      park(T, X, IQ, IB);
     }
-    x_own[0 * XPITCH] = u0;                     // row s0 -> slot 0
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double uw = x_w[0 * XPITCH], ue = x_e[0 * XPITCH];
     double ny_prev = FAST ? normalised4(u0, um2, um + um) : normalised<false>(u0 - um, central(um2, u0));  // ny at row s0-1
     // kappa_y(0, .) = 0 (:372): on the image's first row ny_prev is set to that row's own ny,
     // computed with the very expression the row uses, so ny - ny_prev is exactly 0 there
-    if (s0 == 0) ny_prev = FAST ? normalised4(q[0], um, u0 + u0) : normalised<false>(q[0] - u0, central(um, q[0]));
+    if (s0 == 0) {
+      const double up0 = x_own[0];              // row 1
+      ny_prev = FAST ? normalised4(up0, um, u0 + u0) : normalised<false>(up0 - u0, central(um, up0));
+    }
 
     // one row of the march; `live` (wave-uniform) is false only for rows past the strip end
-    auto row = [&](int i, int g, int k, bool live) {
-      const int t = 4 * g + k;                  // step within the loop body (static after unrolling)
-      const double up = q[t];
-      if (RING8) { u0 = q[(t + 7) & 7]; um = q[(t + 6) & 7]; }
-      // row i+1: publish this lane's value, fetch its neighbours for the next step
-      if (k == 3) *x_ext = xq[(g + 1) % G];     // extras of the next group's rows
-      x_own[((k + 1) & 3) * XPITCH] = up;
-      // the row buffer is exchanged between LANES of this wave: LDS operations of one wave
-      // execute in order, the fences only stop the compiler from reordering them
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double uw_n = x_w[((k + 1) & 3) * XPITCH], ue_n = x_e[((k + 1) & 3) * XPITCH];
-#ifdef CVH_ABLATE_COMPUTE  // diagnostic build: the memory/LDS instruction stream without the arithmetic
-      if (FAST) {
-        const double un_ = u0 + (up + um + uw + ue) * 1e-30 + (double)im[0][k] * 1e-30;
-        if (lane_valid) (live ? a.u_out + (size_t)i * w : a.dummy)[colc] = un_;
-        acc[0] += un_;
-        q[(t + 6) & 7] = U(i + 7);
-        uw = uw_n; ue = ue_n;
-        return;
-      }
-#endif
+    auto row = [&](int i, int k, bool live) {
+      // row i+1 (own column and its x-neighbours, the latter for the next step) from ring slot k
+      const double up = x_own[k * XPITCH];
+      const double uw_n = x_w[k * XPITCH], ue_n = x_e[k * XPITCH];
       double nx, ny;
       if (FAST) {
         const double u02 = u0 + u0;
@@ -411,7 +400,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       if (FAST) hv = heaviside_centred_fast(un, a.inv_eps, fc, satan);   // H - 1/2: see finalize()
       else hv = heaviside_strict(un, eps);
       // rows past the strip end (wave-uniform) get an empty buffer: every lane is out of range
-      buf_store_f64(un, make_rsrc(live ? a.u_out : a.dummy, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+      buf_store_f64(un, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {  // halo / out-of-image lanes are zeroed once after the loop
         acc[0] += hv;
         if (!FAST) acc[1] += (1 - hv);
@@ -428,26 +417,20 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         else acc[2 + 2 * C] += ud * ud;        // :993
         ny_prev = ny;
       }
-      // refill the pipeline: row i+5 of u, row i+4 of the image
-      if (RING8) q[(t + 6) & 7] = U(i + 7);     // row i-1 is dead: its slot takes the row 8 below it
-      else q[t] = U(i + 1 + 4 * G);
-      if (!IMGV) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) im[ch][k] = IM(ch, i + 4);
-      }
-      if (!RING8) { um = u0; u0 = up; }
+      um = u0; u0 = up;
       uw = uw_n; ue = ue_n;
     };
 
     int prio = 3;
     if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
-    for (int ib0 = s0; ib0 < s1; ib0 += 4 * G) {
-#pragma unroll
-     for (int g = 0; g < G; ++g) {
-      const int ib = ib0 + 4 * g;
-      if (ib >= s1 && !a.wave_sync) break;
+    // INTERIOR groups (all four rows inside the strip, every requested row inside the image) run a
+    // branch-free copy of the body: no index clamps, no dead rows -- and no control flow around the
+    // vector-memory operations, which keeps hipcc's vmcnt counts exact (at a join it assumes the
+    // path with the fewest operations in flight).  The groups at the end of a strip take the
+    // general copy.
+    auto group = [&](int ib, auto interior_tag) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
       if (a.wave_sync) __builtin_amdgcn_s_barrier();
-      if (ib >= s1) continue;
       if (a.wave_prio) {
         // Equal-work waves drift apart under oldest-first issue arbitration and the tail then
         // runs at 1-2 waves per SIMD.  Waves that are AHEAD lower their priority (by quarter of
@@ -455,7 +438,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         const int rem = s1 - ib, len = s1 - s0;
         int pq;
         if (a.wave_prio == 1) pq = (rem * 4 - 1) / len;  // 3,2,1,0 by quarters of the strip
-        else {  // thresholds crowd towards the end: only the last level's length sets the finishing spread
+        else {  // thresholds crowd towards the end
           const int sh = a.wave_prio == 4 ? 1 : a.wave_prio;  // 2: 1/4,1/8,1/16 of the strip left; 3: 1/2,1/4,1/8; 4: 1/8,1/16,1/32
           pq = (rem << (4 - sh)) > len ? 3 : ((rem << (5 - sh)) > len ? 2 : ((rem << (6 - sh)) > len ? 1 : 0));
         }
@@ -467,16 +450,28 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
           else __builtin_amdgcn_s_setprio(0);
         }
       }
-      if (IMGV) {
-        IMTILE(g);                              // image bytes of THIS group (requested G groups ago)
-        IMQ(g, ib + 4 * G);                     // request the group 4G rows ahead
+      // requests for the next group (rows ib+4 .. ib+7; its `up` rows are ib+5 .. ib+8)
+      double T[4];
+      u32x4_t IQ[C];
+      int IB[C][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[j] = INTERIOR ? buf_load_f64(ru, voff_u, (unsigned)(ib + 5 + j) * rowbytes) : U(ib + 5 + j);
+      const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + 5) * rowbytes) : UX(ib + 5);
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        if (IMGV) IQ[ch] = INTERIOR ? __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.img[ch], (unsigned)h * (unsigned)w), voff_i, (unsigned)(ib + 4) * (unsigned)w, 0) : IMQ(ch, ib + 4);
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) IB[ch][k] = IM(ch, ib + 4 + k);
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) row(ib + k, g, k, (ib + k) < s1);
-      // extras 4G rows ahead of the group that follows (consumed at its k == 3 ... one turn later)
-      xq[(g + 1) % G] = UX(ib + 4 + 4 * G);
-     }
-    }
+      for (int k = 0; k < 4; ++k) row(ib + k, k, INTERIOR ? true : (ib + k) < s1);
+      park(T, X, IQ, IB);
+    };
+    int ib = s0;
+    for (; ib + 4 <= s1 && ib + 8 < h; ib += 4) group(ib, std::true_type{});
+    for (; ib < s1; ib += 4) group(ib, std::false_type{});
     // exact: valid lanes are multiplied by 1, halo / out-of-image lanes by 0
     const double vmask = lane_valid ? 1.0 : 0.0;
 #pragma unroll
@@ -521,13 +516,8 @@ hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
     if (cap > lds) lds = cap;
   }
   const bool imgv = a.w % 16 == 0 && a.w >= 80 && a.wave_imgv;
-  if (a.wave_depth >= 8) {
-    if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, 2>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-    else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, 2>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-  } else {
-    if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-    else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-  }
+  if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
   return hipGetLastError();
 }
 
