@@ -36,6 +36,7 @@ struct cvh_context {
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_depth = 4;
   double *d_dummy = nullptr;
+  int wave_rev = 0, wave_xcd = 1;
   int wave_skew = 0;            // per-mille: older workgroups get longer strips (see upload_strip_bounds)
   int *d_bounds = nullptr;      // wave kernel: first row of every strip, [tiles_y + 1]
   int bounds_key[4] = {-1, -1, -1, -1};
@@ -250,16 +251,20 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
     c->pm_strip_rows = (int)value;
   } else if (!strcmp(key, "wave_occupancy")) {
-    if (value < 4 || value > 8) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 4..8");
+    if (value < 4 || value > 5) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 4 or 5 (more waves per SIMD would spill registers)");
     c->wave_minw = (int)value;
   } else if (!strcmp(key, "debug_times")) {
     // diagnostic: per-wave start/end stamps of the wave kernel, read back with cvh_debug_read
     if (c->d_dbg) { HIPCHK(c, hipFree(c->d_dbg)); c->d_dbg = nullptr; c->dbg_words = 0; }
     if (value > 0) {
-      c->dbg_words = (size_t)c->partial_rows * 17 + 16;
+      c->dbg_words = (size_t)c->partial_rows * 20 + 16;
       HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
       HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
     }
+  } else if (!strcmp(key, "wave_xcd")) {
+    c->wave_xcd = value != 0;
+  } else if (!strcmp(key, "wave_rev")) {
+    c->wave_rev = value != 0;
   } else if (!strcmp(key, "wave_skew")) {
     if (value < 0 || value > 500) return fail(c, CVH_ERR_ARG, "wave_skew must be 0..500 (per mille)");
     c->wave_skew = (int)value;
@@ -512,6 +517,8 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;
   a->strip_bounds = c->d_bounds;
+  a->wave_rev = c->wave_rev;
+  a->wave_xcd = c->wave_xcd;
   a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
   a->inv_eps = 1.0 / c->p.eps;
@@ -523,6 +530,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
     a->far_k[2] = (e * e2 * e2) / (5.0 * pi); a->far_k[3] = -(e * e2 * e2 * e2) / (7.0 * pi);
     a->far_thr = 64.0 * e;
   }
+  a->stop_cond = c->stop_cond_h;
   a->npix = (double)c->n;
   for (int k = 0; k < CVH_MAX_CHANNELS; ++k) a->sum_img[k] = c->sum_img[k];
   a->derive_complement = use_fast(c) ? (g.strip == 2 ? 2 : 1) : 0;  // 2: the wave kernel sums H - 1/2

@@ -2,6 +2,7 @@
 // Citations are file:line in the reference repository.
 #pragma once
 #include "cvh_internal.h"
+#include <type_traits>
 
 namespace cvh_dev {
 
@@ -95,16 +96,38 @@ __device__ __forceinline__ double atan_table(double x, const double *tab /*LDS [
 
 // Adds acc[] over the workgroup in a fixed order; on return threads tid < NS hold the
 // workgroup total of sum tid in `total` (others undefined).
+// Sum of v over the 64 lanes of the wave, the same value in every lane, by a FIXED tree: xor-1, xor-2
+// inside each quad, rotate-by-4 and rotate-by-8 inside each row of 16 (DPP moves: no LDS round trips),
+// then ((row0 + row1) + row2) + row3 through scalar registers.  This reduction sits on the critical
+// path between two iterations (end of the last wave -> partial row -> ticket -> finalisation).
+__device__ __forceinline__ double wave_sum(double v)
+{
+  auto dpp = [](double x, auto ctrl_tag) {
+    constexpr int ctrl = decltype(ctrl_tag)::value;
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), ctrl, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x124>{});  // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{});  // row_ror:8
+  return ((read_lane(v, 0) + read_lane(v, 16)) + read_lane(v, 32)) + read_lane(v, 48);
+}
+
+// Adds acc[] over the workgroup in a fixed order; on return threads tid < NS hold the
+// workgroup total of sum tid in `total` (others undefined).
 template <int NS>
 __device__ __forceinline__ double block_reduce(double (&acc)[NS], double *sred /*[4*NS]*/)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double v[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    double v = acc[s];
+  for (int s = 0; s < NS; ++s) v[s] = wave_sum(acc[s]);
+  if (lane == 0) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) sred[wave * NS + s] = v;
+    for (int s = 0; s < NS; ++s) sred[wave * NS + s] = v[s];
   }
   __syncthreads();
   double total = 0;
@@ -120,21 +143,36 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
 {
   constexpr int NS = cvh_nsums(C);
   const int tid = threadIdx.x;
+  // The finalising workgroup sits on the critical path of every iteration: the state words
+  // thread 0 needs are requested before the partial rows and the stop condition is a launch argument.
+  int t_pref = 0;
+  double c_old[2 * C];
+  if (tid == 0 && !is_init) {
+    t_pref = a.st->steps_done;
+    if (a.trace) {
+#pragma unroll
+      for (int k = 0; k < C; ++k) { c_old[k] = a.st->c1[k]; c_old[C + k] = a.st->c2[k]; }
+    }
+  }
   double acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0;
-  // Eight partial rows per thread are requested before the first is added (one L2 round trip per
-  // eight rows instead of one per row); the order of the additions is fixed.
-  constexpr int UNR = 8;
+  // Six partial rows per thread are requested before the first is added (one memory round trip per
+  // six rows instead of one per row); the order of the additions is fixed.
+  constexpr int UNR = 6;   // 6 x NS doubles in flight per thread: fits the step kernels' register caps
+  const bool derived = a.derive_complement && !is_init;  // FAST flavour: sums [1], [2+C..2+2C) are derived, their slots hold zeros
   for (int b0 = tid; b0 < a.nparts; b0 += CVH_BLOCK * UNR) {
     double v[UNR][NS];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int b = b0 + u * CVH_BLOCK;
-      const int bc = b < a.nparts ? b : b0;
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
-        v[u][s] = __hip_atomic_load(&a.partials[(size_t)bc * NS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int s = 0; s < NS; ++s) {
+        const bool unused = derived && (s == 1 || (s >= 2 + C && s < 2 + 2 * C));
+        v[u][s] = 0.0;
+        if (b < a.nparts && !unused)
+          v[u][s] = __hip_atomic_load(&a.partials[(size_t)b * NS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -144,7 +182,9 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
       }
     }
   }
+  if (a.dbg_times && tid == 0 && !is_init) a.dbg_times[(size_t)a.nparts * 18 + 2] = __builtin_amdgcn_s_memrealtime();
   const double total = block_reduce<NS>(acc, sred);
+  if (a.dbg_times && tid == 0 && !is_init) a.dbg_times[(size_t)a.nparts * 18 + 3] = __builtin_amdgcn_s_memrealtime();
   if (tid < NS) sfin[tid] = total;
   __syncthreads();
   if (tid == 0) {
@@ -161,17 +201,18 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
     }
     if (!is_init) {
       const double nrm = sqrt(sfin[2 + 2 * C]);
-      const int t = st->steps_done;  // index of the step just executed
+      const int t = t_pref;  // index of the step just executed
       if (a.trace && t < a.trace_cap) {
         double *row = a.trace + (size_t)t * (2 * C + 1);
-        for (int k = 0; k < C; ++k) { row[k] = st->c1[k]; row[C + k] = st->c2[k]; }
+        for (int k = 0; k < C; ++k) { row[k] = c_old[k]; row[C + k] = c_old[C + k]; }
         row[2 * C] = nrm;
       }
       st->norm = nrm;
       st->steps_done = t + 1;
-      if (nrm <= st->stop_cond) st->stopped = 1;  // src/main.cpp:1000, after the update
+      const int stop_now = nrm <= a.stop_cond;  // src/main.cpp:1000, after the update
+      if (stop_now) st->stopped = 1;
       if (a.host_status) {  // the host polls these two words in pinned memory instead of copying the state back
-        __hip_atomic_store(&a.host_status[1], st->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -198,6 +239,7 @@ __device__ __forceinline__ void publish_partials_and_maybe_finalize(const CvhSte
   if (!a.fused_finalize) return;
   if (tid < 64) {  // the storing wave is the signalling wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)nblocks * 19 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
       const unsigned t = __hip_atomic_fetch_add(&a.st->ticket, 1u, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
@@ -208,8 +250,15 @@ __device__ __forceinline__ void publish_partials_and_maybe_finalize(const CvhSte
       }
     }
   }
+  if (a.dbg_times && tid == 0) {  // diagnostic stamps: after the partial row is out, after the ticket
+    a.dbg_times[(size_t)nblocks * 17 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  }
   __syncthreads();
-  if (*s_last) finalize<C>(a, 0, sred, sfin);
+  if (*s_last) {
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)nblocks * 18] = __builtin_amdgcn_s_memrealtime();
+    finalize<C>(a, 0, sred, sfin);
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)nblocks * 18 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 

@@ -28,14 +28,14 @@ namespace {
 
 constexpr int WCOLS = 63;   // output columns per wave
 constexpr int XPITCH = 66;  // exchange row: [0] = col-2 of lane 0, [1..64] = lanes, [65] = col+1 of lane 63
-constexpr int XSLOTS = 4;
 constexpr int IMGP = 80;     // bytes per row of the per-wave image tile (5 x 16-byte pieces)
 
-template <int C, bool FAST, bool LUT>
+template <int C, bool FAST, bool LUT, int G>
 struct WaveSmem {
+  static constexpr int R = 4 * G;                                          // rows per group = ring slots
   static constexpr int NS = cvh_nsums(C);
   static constexpr int off_x = 0;                                          // 4 waves x XSLOTS x XPITCH
-  static constexpr int wave_doubles = XSLOTS * XPITCH + 64 + C * 4 * IMGP / 8;  // row slots + scratch + image tile
+  static constexpr int wave_doubles = R * XPITCH + 64 + C * R * IMGP / 8;  // row slots + scratch + image tile
   static constexpr int off_red = off_x + 4 * wave_doubles;                 // 4*NS
   static constexpr int off_fin = off_red + 4 * NS + (4 * NS) % 2;          // NS
   static constexpr int off_atan = off_fin + NS + NS % 2;                   // FAST: CVH_ATAN2_N
@@ -64,23 +64,33 @@ struct FarCoef { double k0, k1, k2, k3, thr; };
 
 // H_eps(u) - 1/2 = copysign(atan(|u|/eps)/pi, u).  The sums carry this CENTRED value (the
 // finalisation adds N/2 and sum(I)/2, exact integers or half-integers): one addition less per pixel.
-__device__ __forceinline__ double heaviside_centred_fast(double u, double inv_eps, const FarCoef &fc,
-                                                         const double *tab /*LDS, CVH_ATAN2_N*/)
+//
+// Far field (|u| >= 64 eps; with the reference's default time step that is every pixel away from
+// the contour after a handful of iterations): atan(a) = pi/2 - atan(1/a), a = |u|/eps, and the
+// series of atan(t), t = eps/|u| <= 1/64, truncated after t^7/7 (next term < 7e-18) needs one
+// reciprocal and no table.  With r = 1/|u|:
+//   atan(eps r)/pi = r (k0 + r^2 (k1 + r^2 (k2 + r^2 k3))), k_i = (-1)^i eps^(2i+1)/((2i+1) pi).
+// The argument is CLAMPED to the far field so that the formula stays finite on every lane: the
+// march evaluates it unconditionally (no branch inside a row: a group of 4 rows is one basic block
+// and hipcc overlaps the rows' dependent chains), and the rare lanes with |u| < 64 eps are
+// corrected per group by near_field_correction().
+__device__ __forceinline__ double heaviside_centred_far(double u, const FarCoef &fc)
 {
-  // Far field, decided per WAVE (uniform branch): with the reference's default time step the
-  // level set sits at |u| >> 64 eps everywhere after a handful of iterations.  There
-  // atan(a) = pi/2 - atan(1/a), a = |u|/eps, and the series of atan(t), t = eps/|u| <= 1/64,
-  // truncated after t^7/7 (next term < 7e-18) needs one reciprocal and no table.  In terms of
-  // r = 1/u (signed): atan(eps r)/pi = r (k0 + r^2 (k1 + r^2 (k2 + r^2 k3))), k_i = (-1)^i eps^(2i+1)/((2i+1) pi).
-  if (__builtin_amdgcn_ballot_w64(fabs(u) < fc.thr) == 0ull) {
-    const double r0 = __builtin_amdgcn_rcp(u);
-    const double r = __builtin_fma(__builtin_fma(-u, r0, 1.0), r0, r0);
-    const double r2 = r * r;
-    double p = fma3(r2, fc.k3, fc.k2);
-    p = fma3(p, r2, fc.k1);
-    p = fma3(p, r2, fc.k0);
-    return __builtin_fma(-r, p, __builtin_copysign(0.5, u));
-  }
+  const double au = fmax(fabs(u), fc.thr);
+  const double r0 = __builtin_amdgcn_rcp(au);
+  const double r = __builtin_fma(__builtin_fma(-au, r0, 1.0), r0, r0);
+  const double r2 = r * r;
+  double p = fma3(r2, fc.k3, fc.k2);
+  p = fma3(p, r2, fc.k1);
+  p = fma3(p, r2, fc.k0);
+  return __builtin_copysign(__builtin_fma(-r, p, 0.5), u);
+}
+
+// Table form for |u| < 64 eps (valid for any u): atan(a) = pi/4 + atan((a-1)/(a+1)); with
+// y ~ (a-1)/(a+1) rounded to c = j/128, atan(y) = atan(c) + atan(z), z = (n - c d)/(d + c n),
+// n = a-1, d = a+1: ONE accurate reciprocal (of d + c n) and one raw one (to pick c).  |z| <= 1/256.
+__device__ __forceinline__ double heaviside_centred_near(double u, double inv_eps, const double *tab /*LDS, CVH_ATAN2_N*/)
+{
   const double x = u * inv_eps;
   const double a = fmin(fabs(x), 1e300);
   const double n = a - 1.0, d = a + 1.0;
@@ -94,7 +104,7 @@ __device__ __forceinline__ double heaviside_centred_fast(double u, double inv_ep
   const double r = __builtin_fma(__builtin_fma(-den, r0, 1.0), r0, r0);
   const double z = num * r;
   const double z2 = z * z;
-  const double p = fma3(z2, 0.2, -1.0 / 3.0);
+  const double p = __builtin_fma(z2, 0.2, -1.0 / 3.0);
   const double az = __builtin_fma(z * z2, p, z);
   const double atpi = __builtin_fma(az, 1.0 / kPi, tab[j + 128]);  // atan(a)/pi in [0, 1/2]
   return __builtin_copysign(atpi, x);
@@ -118,6 +128,12 @@ __device__ __forceinline__ double normalised4(double fwd, double bwd, double cen
 // (An `if (lane_valid)` store is a control-flow diamond; a store hidden in inline assembly is not
 // counted, and every counted wait then also drains the stores and the younger loads: measured,
 // waves spent 50 % of their cycles in s_waitcnt -- profiles/README.md.)
+#ifndef CVH_LOAD_AUX
+#define CVH_LOAD_AUX 0
+#endif
+#ifndef CVH_STORE_AUX
+#define CVH_STORE_AUX 0
+#endif
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0x80000000u;   // beyond any buffer this kernel accepts (< 2 GiB)
@@ -126,13 +142,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000 /* raw, 32-bit data format (gfx950) */);
 }
+// Diagnostic builds (tools/abl_bench.sh; results are wrong by design): -DCVH_ABLATE_MEMORY replaces every
+// global load of the march by two integer instructions and drops the stores; -DCVH_ABLATE_COMPUTE keeps
+// the memory and LDS traffic and drops the arithmetic of a row.
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+#ifdef CVH_ABLATE_MEMORY
+  return __builtin_bit_cast(double, 0x4000000000000000ull | (unsigned long long)(voff + soff));
+#else
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, CVH_LOAD_AUX));
+#endif
+}
+__device__ __forceinline__ u32x4_t buf_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+#ifdef CVH_ABLATE_MEMORY
+  const unsigned v = (voff + soff) * 0x9e3779b1u;
+  return u32x4_t{v, v ^ 0x55aa55aau, v + 0x01020304u, v};
+#else
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+#endif
 }
 __device__ __forceinline__ void buf_store_f64(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
+#ifndef CVH_ABLATE_MEMORY
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, CVH_STORE_AUX);
+#endif
 }
 
 __device__ __forceinline__ double dpp_from_left(double v)
@@ -150,7 +184,8 @@ __device__ __forceinline__ double dpp_from_left(double v)
 template <int C, bool FAST, bool LUT, int MINW, bool IMGV, int G>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStepArgs a)
 {
-  using L = WaveSmem<C, FAST, LUT>;
+  using L = WaveSmem<C, FAST, LUT, G>;
+  constexpr int R = 4 * G;   // rows per group
   constexpr int NS = cvh_nsums(C);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *sred = smem + L::off_red;
@@ -199,7 +234,16 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   // ---- this wave's strip: workgroup = 4 adjacent wave-columns of one strip
   const int nwc = a.tiles_x;           // wave-columns per image row
   const int nbc = (nwc + 3) >> 2;      // workgroups per strip
-  const int wc = (blockIdx.x % nbc) * 4 + wave, ws = blockIdx.x / nbc;
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  wave_xcd:
+  // renumber them so that an XCD works on a contiguous run of workgroups (neighbouring wave-columns
+  // of the same strips): halo columns and shared image pieces then hit in that XCD's L2.
+  int bid = (int)blockIdx.x;
+  if (a.wave_xcd) {
+    const int nb = (int)gridDim.x, x = bid & 7, j = bid >> 3, q = nb >> 3, r = nb & 7;
+    bid = x * q + (x < r ? x : r) + j;
+  }
+  const int wc = (bid % nbc) * 4 + wave;
+  const int ws = a.wave_rev ? a.tiles_y - 1 - bid / nbc : bid / nbc;
   const int s0 = a.strip_bounds[ws];
   const bool active = wc < nwc;        // the last workgroup of a strip may hold idle waves
   const int col = WCOLS * wc - 1 + lane;                // lane 0 = left halo column
@@ -212,11 +256,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     // image lanes are pointed at a dummy location instead of being masked off): the
     // instruction stream is straight-line, so the compiler's counted vmcnt waits let the
     // 4-row-deep load pipeline and the stores stay in flight.
-    const bool xlane = lane < 8;
-    const int xrow = xlane ? (lane >> 1) & 3 : 0, xside = lane & 1;
+    const bool xlane = lane < 2 * R;
+    const int xrow = xlane ? (lane >> 1) & (R - 1) : 0, xside = lane & 1;
     const int xcol = !xlane ? colc : (xside ? clampi(WCOLS * wc + 63, 0, w - 1) : clampi(WCOLS * wc - 2, 0, w - 1));
     double *x_own = xs + 1 + lane;
-    double *x_ext = xlane ? xs + xrow * XPITCH + (xside ? 65 : 0) : xs + XSLOTS * XPITCH + lane;  // lanes >= 8: scratch
+    double *x_ext = xlane ? xs + xrow * XPITCH + (xside ? 65 : 0) : xs + R * XPITCH + lane;  // other lanes: scratch
     const double *x_w = xs + lane, *x_e = xs + lane + 2;
     const unsigned rowbytes = (unsigned)w * 8u, ubytes = (unsigned)h * rowbytes;   // < 2 GiB (launcher)
     const unsigned voff_u = (unsigned)colc * 8u;                  // byte offset of this lane's column in a row
@@ -224,17 +268,16 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u_in, ubytes);
 
     // row base pointers are wave-uniform (scalar); the lane contributes a constant 32-bit offset
-#ifdef CVH_ABLATE_MEMORY   // diagnostic build: no global loads/stores in the loop (results are wrong)
-    auto U = [&](int r) -> double { return (double)(r & 15) * 0.37 + (double)colc * 0.001; };
-#else
-    auto U = [&](int r) -> double { return buf_load_f64(ru, voff_u, (unsigned)clampi(r, 0, h - 1) * rowbytes); };
-#endif
+    // rows past the strip's last neighbour row (s1) are never used: requests for them (the pipeline runs
+    // up to 8 rows ahead) are pointed at row s1, which is cached -- no HBM traffic beyond the strip
+    const int ulast = s1 < h - 1 ? s1 : h - 1, ilast = s1 - 1;
+    auto U = [&](int r) -> double { return buf_load_f64(ru, voff_u, (unsigned)clampi(r, 0, ulast) * rowbytes); };
     const unsigned voff_x = ((unsigned)xrow * (unsigned)w + (unsigned)xcol) * 8u;
     auto UX = [&](int r0) -> double {   // r0 >= 0; away from the bottom edge the lane's offset is a constant
-      if (r0 + 3 < h) return buf_load_f64(ru, voff_x, (unsigned)r0 * rowbytes);
-      return buf_load_f64(ru, ((unsigned)clampi(r0 + xrow, 0, h - 1) * (unsigned)w + (unsigned)xcol) * 8u, 0u);
+      if (r0 + R - 1 <= ulast) return buf_load_f64(ru, voff_x, (unsigned)r0 * rowbytes);
+      return buf_load_f64(ru, ((unsigned)clampi(r0 + xrow, 0, ulast) * (unsigned)w + (unsigned)xcol) * 8u, 0u);
     };
-    auto IM = [&](int k, int r) -> int { const uint8_t *rp = a.img[k] + (size_t)clampi(r, 0, h - 1) * w; return rp[colc]; };
+    auto IM = [&](int k, int r) -> int { const uint8_t *rp = a.img[k] + (size_t)clampi(r, 0, ilast) * w; return rp[colc]; };
 
     // ---- data flow of the march (G = 1)
     // Global loads never stay in flight across the loop back-edge.  Each iteration handles a GROUP of
@@ -246,11 +289,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     // it would otherwise copy registers and wait for ALL outstanding loads (vmcnt(0)) -- the earlier
     // register-ring form drained its pipeline once per group that way.
     // Ring slot j holds row ib+1+j (66 doubles: west extra, 64 lanes, east extra).
-    int im[C][4];
-    unsigned char *simg = reinterpret_cast<unsigned char *>(xs + XSLOTS * XPITCH + 64);
+    int im[C][R];
+    unsigned char *simg = reinterpret_cast<unsigned char *>(xs + R * XPITCH + 64);
     const int icol0 = (WCOLS * wc - 1) & ~15;                      // 16-byte aligned start column (may be < 0)
     const int ipiece = lane % 5, irow = lane / 5;                  // lanes 0..19: piece of row irow
-    const bool ilane = lane < 20;
+    const bool ilane = lane < 5 * R;
     int ipc = icol0 + 16 * ipiece;
     ipc = ipc < 0 ? 0 : (ipc > w - 16 ? w - 16 : ipc);             // clamped pieces only feed clamped columns
     const int ibyte = colc - icol0;                                // this lane's byte within a tile row (0..79)
@@ -263,8 +306,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     // load per row (measured: the byte loads alone cost ~18 us of a 4096^2 launch).
     auto IMQ = [&](int ch, int r0) -> u32x4_t {
       const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[ch], (unsigned)h * (unsigned)w);
-      if (r0 + 3 < h) return __builtin_amdgcn_raw_buffer_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w, 0);
-      return __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, h - 1) * (unsigned)w + (unsigned)ipc, 0u, 0);
+      if (r0 + R - 1 <= ilast) return buf_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w);
+      return buf_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, ilast) * (unsigned)w + (unsigned)ipc, 0u);
     };
     auto lds_fence = [&]() {
       // the ring is exchanged between LANES of this wave: LDS operations of one wave execute in
@@ -274,22 +317,22 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // parks the next group's data: rows T[j] -> slot j, extras, image pieces / bytes
-    auto park = [&](const double (&T)[4], double X, const u32x4_t (&IQ)[C], const int (&IB)[C][4]) {
+    auto park = [&](const double (&T)[R], double X, const u32x4_t (&IQ)[C], const int (&IB)[C][R]) {
       lds_fence();                              // all reads of the current group are done
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x_own[j * XPITCH] = T[j];
+      for (int j = 0; j < R; ++j) x_own[j * XPITCH] = T[j];
       *x_ext = X;
       if (IMGV) {
         if (ilane) {
 #pragma unroll
-          for (int ch = 0; ch < C; ++ch) *reinterpret_cast<u32x4_t *>(ipiece_dst + ch * 4 * IMGP) = IQ[ch];
+          for (int ch = 0; ch < C; ++ch) *reinterpret_cast<u32x4_t *>(ipiece_dst + ch * R * IMGP) = IQ[ch];
         }
       }
       lds_fence();
 #pragma unroll
       for (int ch = 0; ch < C; ++ch)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) im[ch][k] = IMGV ? (int)simg[(ch * 4 + k) * IMGP + ibyte] : IB[ch][k];
+        for (int k = 0; k < R; ++k) im[ch][k] = IMGV ? (int)simg[(ch * R + k) * IMGP + ibyte] : IB[ch][k];
     };
 
     // ---- prologue: rows s0-2 .. s0 in registers, rows s0+1 .. s0+4 and the image rows s0 .. s0+3 in LDS
@@ -297,11 +340,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     double um = U(s0 - 1), u0 = U(s0);
     double uw, ue;
     {
-      double T[4];
+      double T[R];
       u32x4_t IQ[C];
-      int IB[C][4];
+      int IB[C][R];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) T[j] = U(s0 + 1 + j);
+      for (int j = 0; j < R; ++j) T[j] = U(s0 + 1 + j);
       const double X0 = UX(s0);                 // extras of rows s0 .. s0+3: only row s0's are used
       const double X = UX(s0 + 1);              // extras of rows s0+1 .. s0+4
 #pragma unroll
@@ -309,7 +352,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         if (IMGV) IQ[ch] = IMQ(ch, s0);
         else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) IB[ch][k] = IM(ch, s0 + k);
+          for (int k = 0; k < R; ++k) IB[ch][k] = IM(ch, s0 + k);
         }
       }
       fill_tables();                            // overlaps the prologue's loads
@@ -329,11 +372,27 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       ny_prev = FAST ? normalised4(up0, um, u0 + u0) : normalised<false>(up0 - u0, central(um, up0));
     }
 
+    // DEFER (builds with register room, <= 4 waves/SIMD): no branch inside a row -- the far-field form is
+    // evaluated on every lane and the lanes near the contour are corrected once per group; a group is
+    // then one basic block and hipcc overlaps the rows.  At 5 waves/SIMD the 8 extra registers would spill,
+    // so that build decides far/near per row with a wave-uniform branch.
+    constexpr bool DEFER = FAST && MINW <= 4;
+    double un_keep[4];                  // DEFER: the group's new values and which lanes were near the contour
+    unsigned long long near_mask[4];
     // one row of the march; `live` (wave-uniform) is false only for rows past the strip end
     auto row = [&](int i, int k, bool live) {
       // row i+1 (own column and its x-neighbours, the latter for the next step) from ring slot k
       const double up = x_own[k * XPITCH];
       const double uw_n = x_w[k * XPITCH], ue_n = x_e[k * XPITCH];
+#ifdef CVH_ABLATE_COMPUTE
+      if (FAST) {
+        const double un_ = u0 + (up + um + uw + ue) * 1e-30 + (double)im[0][k] * 1e-30;
+        buf_store_f64(un_, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+        acc[0] += un_;
+        um = u0; u0 = up; uw = uw_n; ue = ue_n;
+        return;
+      }
+#endif
       double nx, ny;
       if (FAST) {
         const double u02 = u0 + u0;
@@ -397,7 +456,14 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         ud = ud * (eps / (kPi * (eps2 + u0 * u0)));      // :209, :992
       }
       const double un = u0 + ud;                         // :994
-      if (FAST) hv = heaviside_centred_fast(un, a.inv_eps, fc, satan);   // H - 1/2: see finalize()
+      if (FAST && DEFER) {
+        hv = heaviside_centred_far(un, fc);     // H - 1/2 (see finalize()); near lanes are corrected after the group
+        un_keep[k & 3] = un;
+        near_mask[k & 3] = __builtin_amdgcn_ballot_w64(fabs(un) < fc.thr);
+      } else if (FAST) {                        // decided per WAVE (uniform branch)
+        if (__builtin_amdgcn_ballot_w64(fabs(un) < fc.thr) == 0ull) hv = heaviside_centred_far(un, fc);
+        else hv = heaviside_centred_near(un, a.inv_eps, satan);
+      }
       else hv = heaviside_strict(un, eps);
       // rows past the strip end (wave-uniform) get an empty buffer: every lane is out of range
       buf_store_f64(un, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
@@ -451,27 +517,44 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
         }
       }
       // requests for the next group (rows ib+4 .. ib+7; its `up` rows are ib+5 .. ib+8)
-      double T[4];
+      double T[R];
       u32x4_t IQ[C];
-      int IB[C][4];
+      int IB[C][R];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) T[j] = INTERIOR ? buf_load_f64(ru, voff_u, (unsigned)(ib + 5 + j) * rowbytes) : U(ib + 5 + j);
-      const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + 5) * rowbytes) : UX(ib + 5);
+      for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
+      const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
 #pragma unroll
       for (int ch = 0; ch < C; ++ch) {
-        if (IMGV) IQ[ch] = INTERIOR ? __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.img[ch], (unsigned)h * (unsigned)w), voff_i, (unsigned)(ib + 4) * (unsigned)w, 0) : IMQ(ch, ib + 4);
+        if (IMGV) IQ[ch] = INTERIOR ? buf_load_b128(make_rsrc(a.img[ch], (unsigned)h * (unsigned)w), voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ch, ib + R);
         else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) IB[ch][k] = IM(ch, ib + 4 + k);
+          for (int k = 0; k < R; ++k) IB[ch][k] = IM(ch, ib + R + k);
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) row(ib + k, k, INTERIOR ? true : (ib + k) < s1);
+      for (int half = 0; half < G; ++half) {
+#pragma unroll
+        for (int k = 4 * half; k < 4 * half + 4; ++k) row(ib + k, k, INTERIOR ? true : (ib + k) < s1);
+        if (FAST && DEFER && (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+          // near_field_correction: replace the clamped far-field value by the table value on the lanes
+          // with |u| < 64 eps (the sums take the difference)
+#pragma unroll
+          for (int k = 4 * half; k < 4 * half + 4; ++k) {
+            if (near_mask[k & 3] != 0ull && (INTERIOR || (ib + k) < s1)) {
+              const double x = un_keep[k & 3];
+              const double d = (fabs(x) < fc.thr) ? heaviside_centred_near(x, a.inv_eps, satan) - heaviside_centred_far(x, fc) : 0.0;
+              acc[0] += d;
+#pragma unroll
+              for (int ch = 0; ch < C; ++ch) acc[2 + ch] = __builtin_fma((double)im[ch][k], d, acc[2 + ch]);
+            }
+          }
+        }
+      }
       park(T, X, IQ, IB);
     };
     int ib = s0;
-    for (; ib + 4 <= s1 && ib + 8 < h; ib += 4) group(ib, std::true_type{});
-    for (; ib < s1; ib += 4) group(ib, std::false_type{});
+    for (; ib + 2 * R <= ulast; ib += R) group(ib, std::true_type{});   // rows up to ib+2R requested, all needed
+    for (; ib < s1; ib += R) group(ib, std::false_type{});
     // exact: valid lanes are multiplied by 1, halo / out-of-image lanes by 0
     const double vmask = lane_valid ? 1.0 : 0.0;
 #pragma unroll
@@ -482,7 +565,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   }
   if (!active && a.wave_sync) {                // idle waves still meet the per-iteration barrier
     const int s1i = a.strip_bounds[ws + 1];
-    for (int ib = s0; ib < s1i; ib += 4) __builtin_amdgcn_s_barrier();
+    for (int ib = s0; ib < s1i; ib += R) __builtin_amdgcn_s_barrier();
   }
 
   if (a.dbg_times && lane == 0) {  // diagnostic stamps: only ever written to their own buffer
@@ -501,10 +584,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   if (a.dbg_times && tid == 0) a.dbg_times[(size_t)gridDim.x * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int C, bool FAST, bool LUT, int MINW>
-hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
+template <int C, bool FAST, bool LUT, int MINW, int G>
+hipError_t launch_wave_g(const CvhStepArgs &a, hipStream_t s)
 {
-  using L = WaveSmem<C, FAST, LUT>;
+  using L = WaveSmem<C, FAST, LUT, G>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
   // Ask for 1/W of the CU's 160 KiB of LDS: the hardware can then place at most W workgroups on
   // a CU, so a grid of <= W x CUs workgroups spreads evenly instead of packing some CUs fuller
@@ -516,23 +599,29 @@ hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
     if (cap > lds) lds = cap;
   }
   const bool imgv = a.w % 16 == 0 && a.w >= 80 && a.wave_imgv;
-  if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-  else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, 1>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
   return hipGetLastError();
+}
+
+template <int C, bool FAST, bool LUT, int MINW>
+hipError_t launch_wave_v(const CvhStepArgs &a, hipStream_t s)
+{
+  // 8-row groups (wave_depth 8) double the time a request has to land; built where registers allow
+  if constexpr (C == 1 && FAST && LUT) { if (a.wave_depth >= 8) return launch_wave_g<C, FAST, LUT, MINW, 2>(a, s); }
+  return launch_wave_g<C, FAST, LUT, MINW, 1>(a, s);
 }
 
 template <int C>
 hipError_t launch_wave_c(const CvhStepArgs &a, int fast, hipStream_t s)
 {
-  if (!fast) return launch_wave_v<C, false, false, (C == 1 ? 4 : 2)>(a, s);
+  if (!fast) return launch_wave_v<C, false, false, (C == 1 ? 3 : 2)>(a, s);
   if constexpr (C == 3) {  // 9 accumulators, 3 image tiles: fits 168 registers (3 waves/SIMD) without spilling
     return a.use_lut ? launch_wave_v<C, true, true, 3>(a, s) : launch_wave_v<C, true, false, 3>(a, s);
   } else {
-  if (a.wave_minw >= 8) return a.use_lut ? launch_wave_v<C, true, true, 8>(a, s) : launch_wave_v<C, true, false, 8>(a, s);
-  if (a.wave_minw == 7) return a.use_lut ? launch_wave_v<C, true, true, 7>(a, s) : launch_wave_v<C, true, false, 7>(a, s);
-  if (a.wave_minw == 6) return a.use_lut ? launch_wave_v<C, true, true, 6>(a, s) : launch_wave_v<C, true, false, 6>(a, s);
-  if (a.wave_minw == 5) return a.use_lut ? launch_wave_v<C, true, true, 5>(a, s) : launch_wave_v<C, true, false, 5>(a, s);
-  return a.use_lut ? launch_wave_v<C, true, true, 4>(a, s) : launch_wave_v<C, true, false, 4>(a, s);
+    // 5 waves/SIMD (96 registers) is the most this kernel reaches without spilling; 4 is kept for comparison
+    if (a.wave_minw >= 5) return a.use_lut ? launch_wave_v<C, true, true, 5>(a, s) : launch_wave_v<C, true, false, 4>(a, s);
+    return a.use_lut ? launch_wave_v<C, true, true, 4>(a, s) : launch_wave_v<C, true, false, 4>(a, s);
   }
 }
 

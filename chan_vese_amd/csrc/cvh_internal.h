@@ -47,6 +47,7 @@ struct CvhStepArgs {
   double dk1, dk2;               // pi/eps, pi*eps : delta_eps(u) = 1 / (dk1*u^2 + dk2)
   double npix;                   // h*w
   double sum_img[CVH_MAX_CHANNELS];  // exact integer sums of the planes (complements are derived)
+  double stop_cond;              // tol * ||mean_k I_k||_2 (:959), the value also held in CvhState
   double far_k[4], far_thr;      // wave kernel, FAST: far-field series of atan(eps/u)/pi and its threshold 64 eps
   int derive_complement;         // sums [1] and [2+C..] are N - sum H, sum I - sum I H; 2: sums [0], [2..] are of H - 1/2
   int tile_rows;                 // rows per tile of the step kernel
@@ -59,6 +60,8 @@ struct CvhStepArgs {
   int *host_status;              // pinned host memory {steps_done, stopped}: written by the finaliser, polled by the host
   double *dummy;                 // >= max(w, 64) doubles that nobody reads: target of masked-off lanes' stores
   int wave_imgv;                 // wave kernel: 16-byte image pieces through LDS (w % 16 == 0)
+  int wave_xcd;                  // wave kernel: XCD-contiguous workgroup numbering
+  int wave_rev;                  // diagnostic: oldest workgroups take the bottom strips
   const int *strip_bounds;       // wave kernel: first row of each strip, [tiles_y + 1]
   int wave_depth;                // wave kernel: rows of u kept in flight per lane (4 or 8)
   int wave_sync;                 // wave kernel: workgroup barrier every 4 rows

@@ -26,6 +26,15 @@ print("start us: min %.2f p50 %.2f p90 %.2f max %.2f" % (st.min(), np.median(st)
 print("end   us: min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f" % (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
 print("dur   us: min %.2f p50 %.2f max %.2f" % ((en - st).min(), np.median(en - st), (en - st).max()))
 print("block end (after publish/finalize) max us %.2f" % ((blk_end[blk_end > 0].max() - t0) / 100.0))
+tick = buf[nb * 17: nb * 18]; lastw = buf[nb * 18: nb * 18 + 4]; stored = buf[nb * 19: nb * 20]
+lb = int(np.argmax(tick))
+wend_lb = w[lb * 4: lb * 4 + 4, 1].max()
+print("last block %d: waves end %.2f | partial stored %.2f | ticket back %.2f | finalize start %.2f end %.2f | block end %.2f" % (
+    lb, (wend_lb - t0) / 100.0, (stored[lb] - t0) / 100.0, (tick[lb] - t0) / 100.0, (lastw[0] - t0) / 100.0, (lastw[1] - t0) / 100.0, (blk_end[lb] - t0) / 100.0))
+d1 = (stored.astype(np.int64) - w[:, 1].reshape(nb, 4).max(axis=1).astype(np.int64)) / 100.0
+d2 = (tick.astype(np.int64) - stored.astype(np.int64)) / 100.0
+print("finalize: partial rows loaded %.2f, reduced %.2f" % ((lastw[2] - t0) / 100.0, (lastw[3] - t0) / 100.0))
+print("per block: waves end -> stored: p50 %.2f max %.2f ; stored -> ticket: p50 %.2f max %.2f" % (np.median(d1), d1.max(), np.median(d2), d2.max()))
 xcc = w[ok, 3] & 0xf
 hw = w[ok, 2]
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
