@@ -11,6 +11,9 @@
 
 #include "cvh_internal.h"
 
+constexpr int kGraphSteps = 16;   // steps per captured graph (even: the ping-pong parity repeats)
+struct StepGraph { hipGraphExec_t exec = nullptr; CvhStepArgs key[2]; int kind = -1, flavour = -1; };
+
 struct cvh_context {
   int h = 0, w = 0, C = 0, device = 0;
   size_t n = 0;
@@ -37,6 +40,8 @@ struct cvh_context {
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_depth = 4;
   double *d_dummy = nullptr;
   int wave_rev = 0, wave_xcd = 1;
+  int use_graph = 1;
+  StepGraph graphs[2];          // by ping-pong parity of the first step
   int wave_skew = 0;            // per-mille: older workgroups get longer strips (see upload_strip_bounds)
   int *d_bounds = nullptr;      // wave kernel: first row of every strip, [tiles_y + 1]
   int bounds_key[4] = {-1, -1, -1, -1};
@@ -130,6 +135,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_mask) (void)hipFree(c->d_mask);
   if (c->d_atan) (void)hipFree(c->d_atan);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
+  for (int k = 0; k < 2; ++k) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->h_status) (void)hipHostFree(c->h_status);
@@ -261,6 +267,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
       HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
       HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
     }
+  } else if (!strcmp(key, "graph")) {
+    c->use_graph = value != 0;
   } else if (!strcmp(key, "wave_xcd")) {
     c->wave_xcd = value != 0;
   } else if (!strcmp(key, "wave_rev")) {
@@ -450,8 +458,13 @@ static Geometry resolve_geometry(const cvh_context *c)
     g.tiles_x = (c->w + cvh_wave_cols() - 1) / cvh_wave_cols();
     int sr = c->strip_rows;
     if (sr <= 0) {
-      const int occ = c->C == 3 ? 3 : c->wave_minw;  // the 3-channel kernel is compiled for 3 waves/SIMD
+      // waves per SIMD the kernel flavour is compiled for (csv_wave_kernel.hip, launch_wave_c)
+      const int occ = use_fast(c) ? (c->C == 3 ? 3 : c->wave_minw) : (c->C == 3 ? 2 : 3);
       int nstrips = (c->num_cus * occ) / ((g.tiles_x + 3) / 4);
+      // Every strip re-reads 3 halo rows and fills its pipeline once: measured on MI355X (512^2 ..
+      // 4096^2, tools/size_sweep.sh) a full round of resident waves is best at 4096^2 (75 strips) and
+      // 64 strips wherever residency would allow many more (smaller images).
+      if (nstrips > 80) nstrips = 64;
       if (nstrips < 1) nstrips = 1;
       sr = (c->h + nstrips - 1) / nstrips;
       if (sr < 8) sr = 8;  // shorter strips only pay prologue overhead
@@ -602,20 +615,64 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
   return CVH_OK;
 }
 
+static int launch_one_step(cvh_context *c, int in_buf)
+{
+  CvhStepArgs a;
+  fill_args(c, &a, in_buf);
+  const int kind = resolve_geometry(c).strip;
+  if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
+  else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
+  else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
+  if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
+  return CVH_OK;
+}
+
+// A run of kGraphSteps consecutive steps as one hipGraph (launch arguments differ between steps only
+// in the ping-pong parity; step counter, trace row and stop flag live on the device).  Measured on
+// MI355X: back-to-back launches on a stream cost 2.8 us each, graph nodes 1.6 us (tools/launch_probe.hip).
+// The instantiated graph is kept per start parity and rebuilt when any launch argument changed.
+static int ensure_step_graph(cvh_context *c, int parity)
+{
+  StepGraph &g = c->graphs[parity];
+  CvhStepArgs key[2];
+  fill_args(c, &key[0], parity);
+  fill_args(c, &key[1], parity ^ 1);
+  const int kind = resolve_geometry(c).strip, flavour = (use_fast(c) ? 1 : 0) | (c->finalize_mode << 1);
+  if (g.exec && g.kind == kind && g.flavour == flavour && !memcmp(key, g.key, sizeof(key))) return CVH_OK;
+  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = CVH_OK;
+  for (int s = 0; s < kGraphSteps && rc == CVH_OK; ++s) rc = launch_one_step(c, parity ^ (s & 1));
+  hipGraph_t graph = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+  if (rc != CVH_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e_end != hipSuccess || !graph) return fail(c, CVH_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e_end));
+  const hipError_t e_inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e_inst != hipSuccess) { g.exec = nullptr; return fail(c, CVH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e_inst)); }
+  memcpy(g.key, key, sizeof(key));
+  g.kind = kind; g.flavour = flavour;
+  return CVH_OK;
+}
+
 static int enqueue_impl(cvh_context *c, int nsteps)
 {
   {
     const Geometry g = resolve_geometry(c);
     if (g.strip == 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
   }
-  for (int s = 0; s < nsteps; ++s) {
-    CvhStepArgs a;
-    fill_args(c, &a, (c->cur_base + c->enqueued) & 1);
-    const int kind = resolve_geometry(c).strip;
-    if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
-    else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
-    else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
-    if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
+  int s = 0;
+  while (c->use_graph && nsteps - s >= kGraphSteps) {
+    const int parity = (c->cur_base + c->enqueued) & 1;
+    const int rc = ensure_step_graph(c, parity);
+    if (rc != CVH_OK) return rc;
+    HIPCHK(c, hipGraphLaunch(c->graphs[parity].exec, c->stream));
+    c->enqueued += kGraphSteps;
+    s += kGraphSteps;
+  }
+  for (; s < nsteps; ++s) {
+    const int rc = launch_one_step(c, (c->cur_base + c->enqueued) & 1);
+    if (rc != CVH_OK) return rc;
     c->enqueued++;
   }
   return CVH_OK;
