@@ -138,6 +138,8 @@ def main():
                 traffic = None
         workload = (f"{n}x{n} {C}-channel synthetic disk, checkerboard init, {args.steps} CSV iterations, tol 0"
                     + (" (BASELINE configs[1])" if (n, C, args.steps, total_images) == (4096, 1, 500, 1) else ""))
+        kopt = dict(kv.split("=") for kv in (args.opt or [])).get("kernel", "-1")
+        kernel_name = {"0": "csv_step_kernel (tile)", "1": "csv_strip_kernel"}.get(kopt, "csv_wave_kernel")
         out = {
             "metric": "Mpixel-iterations/s (CSV u-update)",
             "value": value,
@@ -156,7 +158,7 @@ def main():
                        "per_rank_mpx_it_s": [r[1] / r[2] / 1e6 for r in records]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "csv_step_kernel", "avg_launch_us": avg_launch_s * 1e6,
+                         "kernel": kernel_name, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

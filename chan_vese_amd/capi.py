@@ -22,7 +22,7 @@ EXPORTS = [
     "cvh_set_params", "cvh_set_option", "cvh_set_image", "cvh_get_image", "cvh_set_levelset",
     "cvh_get_levelset", "cvh_init_checkerboard", "cvh_levelset_checkerboard_host", "cvh_run",
     "cvh_enqueue_steps", "cvh_sync", "cvh_reset_run", "cvh_get_means", "cvh_get_trace",
-    "cvh_get_stop_condition", "cvh_get_mask", "cvh_separate", "cvh_perona_malik",
+    "cvh_get_stop_condition", "cvh_get_mask", "cvh_get_contour", "cvh_separate", "cvh_perona_malik",
     "cvh_pm_trip_count", "cvh_last_run_ms", "cvh_last_pm_ms", "cvh_ppf_apply",
     "cvh_ppf_apply_device", "cvh_version",
 ]
@@ -78,6 +78,7 @@ def lib():
         "cvh_get_trace": (C.c_int, [vp, dp, C.c_int, ip]),
         "cvh_get_stop_condition": (C.c_int, [vp, dp]),
         "cvh_get_mask": (C.c_int, [vp, u8p, C.c_int]),
+        "cvh_get_contour": (C.c_int, [vp, u8p]),
         "cvh_separate": (C.c_int, [vp, u8p, C.c_int, u8p]),
         "cvh_perona_malik": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "cvh_pm_trip_count": (C.c_int, [C.c_double, C.c_double]),
@@ -248,6 +249,11 @@ class Context:
     def get_mask(self, invert=False):
         m = np.empty((self.h, self.w), dtype=np.uint8)
         self._chk(self._L.cvh_get_mask(self._h, _u8p(m), int(bool(invert))))
+        return m
+
+    def get_contour(self):
+        m = np.empty((self.h, self.w), dtype=np.uint8)
+        self._chk(self._L.cvh_get_contour(self._h, _u8p(m)))
         return m
 
     def separate(self, img3, invert=False):

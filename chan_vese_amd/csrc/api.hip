@@ -812,6 +812,18 @@ extern "C" int cvh_get_mask(cvh_context *c, uint8_t *mask, int invert)
   return CVH_OK;
 }
 
+extern "C" int cvh_get_contour(cvh_context *c, uint8_t *contour)
+{
+  if (!c || !contour) return CVH_ERR_ARG;
+  if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_get_contour: no level set");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_mask) HIPCHK(c, hipMalloc((void **)&c->d_mask, c->n));
+  HIPCHK(c, cvh_launch_contour(c->d_u[current_buffer(c)], c->d_mask, c->h, c->w, c->stream));
+  HIPCHK(c, hipMemcpyAsync(contour, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CVH_OK;
+}
+
 extern "C" int cvh_separate(cvh_context *c, const uint8_t *img3, int invert, uint8_t *selection3)
 {
   if (!c || !img3 || !selection3) return CVH_ERR_ARG;

@@ -104,6 +104,7 @@ int cvh_pm_wave_cols();
 hipError_t cvh_launch_pm_store(const double *state, uint8_t *plane, size_t n, hipStream_t s);
 void cvh_pm_grid(int h, int w, int *tiles_x, int *tiles_y);
 
+hipError_t cvh_launch_contour(const double *u, uint8_t *out, int h, int w, hipStream_t s);
 hipError_t cvh_launch_mask(const double *u, uint8_t *mask, size_t n, int invert, hipStream_t s);
 hipError_t cvh_launch_ppf(double *data, size_t n, int op, double eps, hipStream_t s);
 hipError_t cvh_launch_separate(const uint8_t *img3, const double *u, uint8_t *sel3, size_t n,

@@ -49,6 +49,39 @@ __global__ void ppf_kernel(double *data, size_t n, int op, double eps)
 
 }  // namespace
 
+// Contour map of one video frame, src/VideoWriterManager.cpp:60-74: mask = (uint8(round(u)) > 0)
+// (convertTo(CV_8U) rounds half to even and saturates, so mask = rint(u) >= 1), contours by
+// cv::findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) drawn 1 pixel wide with 8-connected lines.
+// Restated (OpenCV is absent; its 2.4 behaviour as recalled: the outermost pixel ring of the mask is
+// cleared before tracing; a border point of an 8-connected component is a 1-pixel with a 0-pixel
+// in its 4-neighbourhood; hole borders are pixels of the surrounding component; the polygonal
+// approximation re-drawn with 8-connected lines covers the traced pixels again): contour(i,j) = 1 where
+// the cleared mask is 1 and one of its 4 neighbours is 0.
+__device__ __forceinline__ int video_mask_at(const double *u, int h, int w, int i, int j)
+{
+  if (i <= 0 || j <= 0 || i >= h - 1 || j >= w - 1) return 0;
+  return __builtin_rint(u[(size_t)i * w + j]) >= 1.0;
+}
+
+__global__ void contour_kernel(const double *u, uint8_t *out, int h, int w)
+{
+  const size_t n = (size_t)h * w;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(q / w), j = (int)(q % w);
+    uint8_t c = 0;
+    if (video_mask_at(u, h, w, i, j))
+      c = !(video_mask_at(u, h, w, i - 1, j) && video_mask_at(u, h, w, i + 1, j) &&
+            video_mask_at(u, h, w, i, j - 1) && video_mask_at(u, h, w, i, j + 1));
+    out[q] = c;
+  }
+}
+
+hipError_t cvh_launch_contour(const double *u, uint8_t *out, int h, int w, hipStream_t s)
+{
+  hipLaunchKernelGGL(contour_kernel, dim3(flat_grid((size_t)h * w)), dim3(256), 0, s, u, out, h, w);
+  return hipGetLastError();
+}
+
 hipError_t cvh_launch_mask(const double *u, uint8_t *mask, size_t n, int invert, hipStream_t s)
 {
   hipLaunchKernelGGL(mask_kernel, dim3(flat_grid(n)), dim3(256), 0, s, u, mask, n, invert);

@@ -4,14 +4,21 @@
 // forms, defaults, multitoken --lambda1/--lambda2, validation order and messages, msg_exit
 // behaviour, output naming through add_suffix) and its orchestration (:877-1007), but every
 // array operation of the hot path goes through include/chanvese_hip.h into HIP kernels.
-// No OpenCV/Boost: images are binary PGM/PPM (formats cv::imread also accepts).
-// Out of scope here (reference GUI/video code): -V/--video, -R/--rectangle, -C/--circle are
-// parsed and validated as in the reference, then rejected with a message.
-// Additions that do not collide with reference options: --dump-u, --dump-mask, --device,
-// --math, --rect (non-interactive rectangle contour: 1 inside / 0 outside as
-// src/InteractiveDataRect.cpp:20-27).
+// No OpenCV/Boost: images are binary PGM/PPM or PNG (png_io.hpp over zlib), formats cv::imread
+// also accepts; outputs keep the input's format like cv::imwrite by extension.
+// Reference GUI code is out of scope: -R/--rectangle and -C/--circle (mouse selection) are parsed
+// and validated as in the reference, then rejected with a message; their non-interactive forms are
+// --rect x,y,w,h (1 inside / 0 outside, src/InteractiveDataRect.cpp:20-27) and --circ cx,cy,r
+// (1-pixel outline of ones on zeros, src/InteractiveDataCirc.cpp:18-25).
+// -V/--video: the XVID writer (src/VideoWriterManager.cpp) is replaced by an image sequence
+// <stem>_frames/frame_NNNNNN<ext> holding the same frames (the input with the contour drawn in
+// --line-color, one frame for t = 0 and one after every iteration, :926-931,:997); the overlay
+// text of -O is not rendered (no font rasteriser here), --fps has nothing to act on.
+// Additions that do not collide with reference options: --dump-u, --dump-mask, --device, --math,
+// --rect, --circ, --verbose.
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -24,7 +31,10 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "chanvese_hip.h"
+#include "png_io.hpp"
 
 namespace {
 
@@ -102,6 +112,51 @@ bool write_pnm(const std::string &path, int h, int w, int channels, const uint8_
   return (bool)out;
 }
 
+// cv::imread / cv::imwrite stand-ins: format by content on input, by extension on output
+bool has_ext(const std::string &path, const char *ext)
+{
+  const size_t n = std::strlen(ext);
+  return path.size() >= n && iequals(path.substr(path.size() - n), ext);
+}
+
+bool read_image(const std::string &path, Image &img, bool &is_png)
+{
+  is_png = pngio::is_png(path);
+  if (!is_png) return read_pnm(path, img);
+  pngio::Decoded d;
+  const std::string err = pngio::read(path, d);
+  if (!err.empty()) { std::cerr << "PNG: " << err << "\n"; return false; }
+  img.h = d.h; img.w = d.w; img.channels = d.channels; img.px.swap(d.px);
+  return true;
+}
+
+bool write_image(const std::string &path, int h, int w, int channels, const uint8_t *px)
+{
+  if (has_ext(path, ".png")) return pngio::write(path, h, w, channels, px);
+  return write_pnm(path, h, w, channels, px);
+}
+
+// cv::circle(u, centre, radius, 1) with the default thickness 1 and 8-connected line type
+// (src/InteractiveDataCirc.cpp:24): OpenCV's integer midpoint circle, restated from memory of
+// drawing.cpp (Circle): parity unpinned.
+void draw_circle_outline(std::vector<double> &u, int h, int w, int cx, int cy, int radius)
+{
+  auto put = [&](int x, int y) { if (x >= 0 && x < w && y >= 0 && y < h) u[(size_t)y * w + x] = 1; };
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    const int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+    const int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+    put(x11, y11); put(x12, y11); put(x11, y12); put(x12, y12);
+    put(x21, y21); put(x22, y21); put(x21, y22); put(x22, y22);
+    dy++;
+    err += plus; plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+}
+
 // ---- option parsing (the subset of boost::program_options behaviour the reference uses) --
 struct Spec { const char *lname; char sname; int kind; };  // kind: 0 switch, 1 one value, 2 multitoken
 const Spec kSpecs[] = {
@@ -112,7 +167,7 @@ const Spec kSpecs[] = {
     {"segment", 'S', 0}, {"grayscale", 'g', 0}, {"video", 'V', 0}, {"overlay-text", 'O', 0},
     {"invert-selection", 'I', 0}, {"select", 's', 0}, {"rectangle", 'R', 0}, {"circle", 'C', 0},
     // additions of this build
-    {"dump-u", 0, 1}, {"dump-mask", 0, 1}, {"device", 0, 1}, {"math", 0, 1}, {"rect", 0, 1}, {"verbose", 0, 0}};
+    {"dump-u", 0, 1}, {"dump-mask", 0, 1}, {"device", 0, 1}, {"math", 0, 1}, {"rect", 0, 1}, {"circ", 0, 1}, {"verbose", 0, 0}};
 
 struct Parsed {
   std::vector<std::pair<std::string, std::vector<std::string>>> opts;
@@ -229,7 +284,7 @@ void print_help()
       "  -T [ --segment-time ] arg (=20)    number of smoothing steps in Perona-Malik\n"
       "  -S [ --segment ]                   segment the image with Perona-Malik beforehand\n"
       "  -g [ --grayscale ]                 read in as grayscale\n"
-      "  -V [ --video ]                     enable video output (not supported in this build)\n"
+      "  -V [ --video ]                     enable video output (here: image sequence <stem>_frames/frame_NNNNNN<ext>)\n"
       "  -O [ --overlay-text ]              add overlay text\n"
       "  -I [ --invert-selection ]          invert selected region (see: select)\n"
       "  -s [ --select ]                    separate the region encolosed by the contour (adds suffix '_selection')\n"
@@ -237,8 +292,9 @@ void print_help()
       "  -C [ --circle ]                    select circular contour interactively (not supported in this build)\n"
       "MI355X build additions:\n"
       "  --rect x,y,w,h                     rectangular initial contour (1 inside, 0 outside)\n"
+      "  --circ cx,cy,r                     circular initial contour (1-pixel outline of ones on zeros)\n"
       "  --dump-u arg                       write the final level set as raw little-endian float64 (h*w)\n"
-      "  --dump-mask arg                    write the final mask ((float)u > 0) as binary PGM (0/255)\n"
+      "  --dump-mask arg                    write the final mask ((float)u > 0) as PGM or PNG by extension (0/255)\n"
       "  --device arg (=0)                  HIP device\n"
       "  --math arg (=fast)                 strict | fast (see include/chanvese_hip.h)\n"
       "  --verbose                          print the iteration count and last norm to stderr\n"
@@ -258,7 +314,7 @@ int main(int argc, char **argv)
   double mu = 0.5, nu = 0, eps = 1, tol = 0.001, dt = 1, fps = 10, K = 10, L = 0.25, T = 20;
   int max_steps = -1, device = 0;
   std::vector<double> lambda1, lambda2;
-  std::string input_filename, text_position = "TL", line_color_str = "blue", dump_u, dump_mask, math = "fast", rect;
+  std::string input_filename, text_position = "TL", line_color_str = "blue", dump_u, dump_mask, math = "fast", rect, circ;
   bool grayscale = false, write_video = false, overlay_text = false, object_selection = false, invert = false,
        segment = false, rectangle_contour = false, circle_contour = false;
 
@@ -284,10 +340,11 @@ int main(int argc, char **argv)
   if (auto v = one("device")) device = to_int("device", *v);
   if (auto v = one("math")) math = *v;
   if (auto v = one("rect")) rect = *v;
+  if (auto v = one("circ")) circ = *v;
   segment = vm.count("segment"); grayscale = vm.count("grayscale"); write_video = vm.count("video");
   overlay_text = vm.count("overlay-text"); invert = vm.count("invert-selection");
   object_selection = vm.count("select"); rectangle_contour = vm.count("rectangle"); circle_contour = vm.count("circle");
-  (void)fps; (void)overlay_text;
+  (void)fps;
 
   // ---- validation, in the reference's order with its messages: src/main.cpp:786-869
   if (vm.count("help")) { print_help(); return EXIT_SUCCESS; }
@@ -327,13 +384,15 @@ int main(int argc, char **argv)
     msg_exit("The segmentation duration must exceed the value of Laplacian coefficient, " + std::to_string(L) + ".");
   if (rectangle_contour && circle_contour) msg_exit("Cannot initialize with both rectangular and circular contour");
   if (rectangle_contour || circle_contour)
-    msg_exit("Interactive contour selection (-R/-C) needs a display and is not supported in this build; use --rect x,y,w,h.");
-  if (write_video) msg_exit("Video output (-V) is not supported in this build.");
+    msg_exit("Interactive contour selection (-R/-C) needs a display and is not supported in this build; use --rect x,y,w,h or --circ cx,cy,r.");
+  if (!rect.empty() && !circ.empty()) msg_exit("Cannot initialize with both rectangular and circular contour");
   if (math != "strict" && math != "fast") msg_exit("error: the argument ('" + math + "') for option '--math' is invalid");
 
   // ---- read the image: src/main.cpp:877-887 (8-bit gray or BGR)
   Image file;
-  if (!read_pnm(input_filename, file)) msg_exit("Error on opening \"" + input_filename + "\" (probably not an image)!");
+  bool input_is_png = false;
+  if (!read_image(input_filename, file, input_is_png)) msg_exit("Error on opening \"" + input_filename + "\" (probably not an image)!");
+  if (!input_is_png && has_ext(input_filename, ".png")) msg_exit("Error on opening \"" + input_filename + "\" (probably not an image)!");
   const int h = file.h, w = file.w;
   const size_t n = (size_t)h * w;
   const int nof_channels = grayscale ? 1 : 3;
@@ -345,8 +404,13 @@ int main(int argc, char **argv)
     if (file.channels == 1) { b = g = r = file.px[q]; }
     else { r = file.px[3 * q]; g = file.px[3 * q + 1]; b = file.px[3 * q + 2]; }
     if (grayscale) {
-      // cv::imread(..., GRAYSCALE) of a colour file: fixed-point BT.601 (R 4899, G 9617, B 1868, >> 14)
-      const uint8_t y = file.channels == 1 ? b : (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+      // cv::imread(..., GRAYSCALE) of a colour file.  PxM decoder: icvCvt_BGR2Gray_8u_C3C1R, 14-bit fixed
+      // point BT.601 (R 4899, G 9617, B 1868).  PNG decoder: libpng's png_set_rgb_to_gray(0.299, 0.587),
+      // 15-bit fixed point (R 9798, G 19235, B 3735, rounded; equal channels pass through).
+      uint8_t y;
+      if (file.channels == 1) y = b;
+      else if (!input_is_png) y = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+      else y = (r == g && g == b) ? r : (uint8_t)((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15);
       img_bgr[3 * q] = img_bgr[3 * q + 1] = img_bgr[3 * q + 2] = y;  // cvtColor GRAY2RGB (:885)
       planes[0][q] = y;
     } else {
@@ -381,8 +445,49 @@ int main(int argc, char **argv)
     for (int i = std::max(ry, 0); i < std::min(ry + rh, h); ++i)
       for (int j = std::max(rx, 0); j < std::min(rx + rw, w); ++j) u[(size_t)i * w + j] = 1;
     cvh_check(ctx, cvh_set_levelset(ctx, u.data()), "cvh_set_levelset");
+  } else if (!circ.empty()) {
+    int cx, cy, cr;
+    if (std::sscanf(circ.c_str(), "%d,%d,%d", &cx, &cy, &cr) != 3 || cr <= 0)  // is_ok(): radius > 0
+      msg_exit("You must specify the contour with non-zero dimensions");
+    std::vector<double> u(n, 0.0);  // src/InteractiveDataCirc.cpp:23-24
+    draw_circle_outline(u, h, w, cx, cy, cr);
+    cvh_check(ctx, cvh_set_levelset(ctx, u.data()), "cvh_set_levelset");
   } else {
     cvh_check(ctx, cvh_init_checkerboard(ctx), "cvh_init_checkerboard");
+  }
+
+  // ---- video frames: src/main.cpp:926-931 (first frame before the channels are split / smoothed)
+  const size_t dot = input_filename.find_last_of('.');
+  const size_t slash = input_filename.find_last_of('/');
+  const bool with_ext = dot != std::string::npos && (slash == std::string::npos || dot > slash + 1);
+  const std::string frames_dir = (with_ext ? input_filename.substr(0, dot) : input_filename) + "_frames";
+  const std::string frame_ext = with_ext ? input_filename.substr(dot) : std::string(".ppm");
+  uint8_t contour_bgr[3] = {255, 0, 0};  // ChanVese::Colors::blue = CV_RGB(0,0,255), src/main.cpp:111-118,747
+  {
+    struct { const char *name; uint8_t r, g, b; } table[] = {{"red", 255, 0, 0}, {"green", 0, 255, 0}, {"blue", 0, 0, 255},
+      {"black", 0, 0, 0}, {"white", 255, 255, 255}, {"magenta", 255, 0, 255}, {"yellow", 255, 255, 0}, {"cyan", 0, 255, 255}};
+    for (auto &e : table) if (iequals(line_color_str, e.name)) { contour_bgr[0] = e.b; contour_bgr[1] = e.g; contour_bgr[2] = e.r; }
+  }
+  int frame_no = 0;
+  std::vector<uint8_t> contour, frame;
+  auto write_frame = [&]() {  // VideoWriterManager::write_frame, src/VideoWriterManager.cpp:40-57
+    contour.resize(n); frame.resize(n * 3);
+    cvh_check(ctx, cvh_get_contour(ctx, contour.data()), "cvh_get_contour");
+    for (size_t q = 0; q < n; ++q) {   // frames are RGB files; img_bgr is the reference's `img`
+      const bool c = contour[q] != 0;
+      frame[3 * q] = c ? contour_bgr[2] : img_bgr[3 * q + 2];
+      frame[3 * q + 1] = c ? contour_bgr[1] : img_bgr[3 * q + 1];
+      frame[3 * q + 2] = c ? contour_bgr[0] : img_bgr[3 * q];
+    }
+    char name[64];
+    std::snprintf(name, sizeof(name), "/frame_%06d", frame_no++);
+    const std::string path = frames_dir + name + (has_ext(frame_ext, ".png") ? ".png" : ".ppm");
+    if (!write_image(path, h, w, 3, frame.data())) msg_exit("Error: cannot write \"" + path + "\"");
+  };
+  if (write_video) {
+    if (mkdir(frames_dir.c_str(), 0777) != 0 && errno != EEXIST) msg_exit("Error: cannot create \"" + frames_dir + "\"");
+    if (overlay_text) std::cerr << "note: overlay text (-O) is not rendered in this build\n";
+    write_frame();
   }
 
   // ---- Perona-Malik: src/main.cpp:940-947
@@ -396,14 +501,25 @@ int main(int argc, char **argv)
       if (nof_channels == 1) out[q] = planes[0][q];
       else { out[3 * q] = planes[2][q]; out[3 * q + 1] = planes[1][q]; out[3 * q + 2] = planes[0][q]; }  // BGR -> RGB file order
     }
-    if (!write_pnm(add_suffix(input_filename, "pm"), h, w, nof_channels, out.data()))
+    if (!write_image(add_suffix(input_filename, "pm"), h, w, nof_channels, out.data()))
       msg_exit("Error: cannot write \"" + add_suffix(input_filename, "pm") + "\"");
   }
 
   // ---- timestep loop: src/main.cpp:950-1001 (stop condition and every iteration on the GPU)
   int steps_done = 0;
   double last_norm = 0;
-  cvh_check(ctx, cvh_run(ctx, max_steps, &steps_done, &last_norm), "cvh_run");
+  if (!write_video) {
+    cvh_check(ctx, cvh_run(ctx, max_steps, &steps_done, &last_norm), "cvh_run");
+  } else {
+    // one iteration per frame; the frame is saved before the stop test (:997-1000)
+    for (int t = 1; t <= max_steps; ++t) {
+      int stopped = 0;
+      cvh_check(ctx, cvh_enqueue_steps(ctx, 1), "cvh_enqueue_steps");
+      cvh_check(ctx, cvh_sync(ctx, &steps_done, &last_norm, &stopped), "cvh_sync");
+      write_frame();
+      if (stopped) break;
+    }
+  }
 
   if (!dump_u.empty()) {
     std::vector<double> u(n);
@@ -416,7 +532,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t> m(n);
     cvh_check(ctx, cvh_get_mask(ctx, m.data(), invert ? 1 : 0), "cvh_get_mask");
     for (auto &v : m) v = v ? 255 : 0;
-    if (!write_pnm(dump_mask, h, w, 1, m.data())) msg_exit("Error: cannot write \"" + dump_mask + "\"");
+    if (!write_image(dump_mask, h, w, 1, m.data())) msg_exit("Error: cannot write \"" + dump_mask + "\"");
   }
 
   // ---- selection: src/main.cpp:1004-1005
@@ -424,7 +540,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t> sel(n * 3), rgb(n * 3);
     cvh_check(ctx, cvh_separate(ctx, img_bgr.data(), invert ? 1 : 0, sel.data()), "cvh_separate");
     for (size_t q = 0; q < n; ++q) { rgb[3 * q] = sel[3 * q + 2]; rgb[3 * q + 1] = sel[3 * q + 1]; rgb[3 * q + 2] = sel[3 * q]; }
-    if (!write_pnm(add_suffix(input_filename, "selection"), h, w, 3, rgb.data()))
+    if (!write_image(add_suffix(input_filename, "selection"), h, w, 3, rgb.data()))
       msg_exit("Error: cannot write \"" + add_suffix(input_filename, "selection") + "\"");
   }
   if (vm.count("verbose"))  // the reference prints nothing

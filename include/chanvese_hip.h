@@ -139,6 +139,11 @@ int cvh_get_stop_condition(cvh_context *ctx, double *stop_cond);
 
 /* mask = ((float)u > 0), optionally 1 - mask: src/main.cpp:395-400. */
 int cvh_get_mask(cvh_context *ctx, uint8_t *mask, int invert);
+/* Contour map of the reference's video frame, VideoWriterManager::draw_contour
+ * src/VideoWriterManager.cpp:60-74: 1 where a frame pixel is painted in the contour colour.
+ * The frame's mask rule differs from cvh_get_mask: uint8(round(u)) > 0.
+ * cv::findContours/drawContours are restated (see misc_kernels.hip); parity unpinned. */
+int cvh_get_contour(cvh_context *ctx, uint8_t *contour);
 /* separate(), src/main.cpp:386-405: img3 and selection3 are interleaved h*w*3 uint8
  * (the reference's CV_8UC3); white canvas with img3 copied where the mask is set. */
 int cvh_separate(cvh_context *ctx, const uint8_t *img3, int invert, uint8_t *selection3);

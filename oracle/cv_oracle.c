@@ -389,6 +389,36 @@ void cvo_mask(const double *u, int h, int w, int invert, uint8_t *mask)
   }
 }
 
+void cvo_video_contour(const double *u, int h, int w, uint8_t *contour)
+{
+  const size_t n = (size_t)h * w;
+  uint8_t *m = (uint8_t *)calloc(n ? n : 1, 1);
+  /* :65-67 u.convertTo(CV_8UC1) = saturate_cast<uchar>(cvRound(x)) (round half to even), then
+   * threshold(> 0 -> 1) */
+  for (size_t q = 0; q < n; ++q) {
+    double r = nearbyint(u[q]);
+    if (!(r > 0)) r = 0;         /* negatives and NaN saturate to 0 */
+    if (r > 255) r = 255;
+    m[q] = ((uint8_t)r) > 0 ? 1 : 0;
+  }
+  /* cvFindContours works on a copy whose first/last rows and columns are cleared */
+  for (int j = 0; j < w; ++j) { m[j] = 0; m[(size_t)(h - 1) * w + j] = 0; }
+  for (int i = 0; i < h; ++i) { m[(size_t)i * w] = 0; m[(size_t)i * w + (w - 1)] = 0; }
+  /* :68-72 every border (outer and hole) of every 8-connected component, redrawn 1 px wide */
+  for (int i = 0; i < h; ++i)
+    for (int j = 0; j < w; ++j) {
+      const size_t q = (size_t)i * w + j;
+      uint8_t c = 0;
+      if (m[q]) {
+        /* inside the cleared ring every 4-neighbour exists */
+        const int zero_nb = !m[q - w] || !m[q + w] || !m[q - 1] || !m[q + 1];
+        c = zero_nb ? 1 : 0;
+      }
+      contour[q] = c;
+    }
+  free(m);
+}
+
 void cvo_separate(const uint8_t *img3, const double *u, int h, int w, int invert,
                   uint8_t *selection3)
 {

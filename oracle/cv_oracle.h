@@ -75,6 +75,12 @@ void cvo_perona_malik_channel(const uint8_t *in, int h, int w, double K, double 
                               double T, uint8_t *out, double *state_out);
 /* src/main.cpp:395-400 mask = ((float)u > 0), optional invert */
 void cvo_mask(const double *u, int h, int w, int invert, uint8_t *mask);
+/* src/VideoWriterManager.cpp:60-74 draw_contour: 1 where the frame gets the contour colour.
+ * convertTo(CV_8U) + threshold + cv::findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) + drawContours
+ * (1 px, 8-connected), restated from Suzuki-Abe border following as OpenCV 2.4 applies it
+ * (outer ring of the mask cleared; border point of an 8-connected component = 1-pixel with a
+ * 0-pixel among its 4 neighbours).  Parity unpinned: no OpenCV in this image. */
+void cvo_video_contour(const double *u, int h, int w, uint8_t *contour);
 /* src/main.cpp:386-405: interleaved 3-channel img (h*w*3) -> selection (h*w*3) */
 void cvo_separate(const uint8_t *img3, const double *u, int h, int w, int invert,
                   uint8_t *selection3);

@@ -71,6 +71,7 @@ def lib():
         L.cvo_perona_malik_channel.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_double,
                                                C.c_double, u8p, dp]
         L.cvo_mask.argtypes = [dp, C.c_int, C.c_int, C.c_int, u8p]
+        L.cvo_video_contour.argtypes = [dp, C.c_int, C.c_int, u8p]
         L.cvo_separate.argtypes = [u8p, dp, C.c_int, C.c_int, C.c_int, u8p]
         _LIB = L
     return _LIB
@@ -193,6 +194,14 @@ def mask(u, invert=False):
     h, w = u.shape
     m = np.empty((h, w), dtype=np.uint8)
     lib().cvo_mask(_dp(u), h, w, int(bool(invert)), _u8p(m))
+    return m
+
+
+def video_contour(u):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    h, w = u.shape
+    m = np.empty((h, w), dtype=np.uint8)
+    lib().cvo_video_contour(_dp(u), h, w, _u8p(m))
     return m
 
 

@@ -255,6 +255,26 @@ def test_mask_and_separate(capi, oracle):
             assert np.array_equal(ctx.separate(img3, inv), oracle.separate(img3, u, inv))
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (2, 7), (3, 3), (33, 47), (150, 528)])
+def test_video_contour(capi, oracle, shape):
+    """cvh_get_contour = the pixels VideoWriterManager::draw_contour paints (src/VideoWriterManager.cpp:60-74):
+    mask rule uint8(round(u)) > 0, half-way cases (0.5, 1.5), negatives, an evolved level set."""
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    u = rng.normal(scale=1.5, size=shape)
+    u.ravel()[: min(6, u.size)] = [0.5, 1.5, -0.5, 0.5000000001, 1e300, -1e300][: min(6, u.size)]
+    with capi.Context(h, w, 1, capi.make_params(tol=0.0)) as ctx:
+        ctx.set_levelset(u)
+        assert np.array_equal(ctx.get_contour(), oracle.video_contour(u))
+        if h >= 33:
+            img = synth.disk(h, 190, 60, noise=8, seed=2, h=h, w=w)
+            ctx.set_image([img]); ctx.init_checkerboard(); ctx.run(12)
+            ue = ctx.get_levelset()
+            c = ctx.get_contour()
+            assert np.array_equal(c, oracle.video_contour(ue))
+            assert c.sum() > 0 and c[0].sum() == 0 and c[:, 0].sum() == 0
+
+
 @pytest.mark.parametrize("op", [0, 1, 2])
 def test_parallel_pixel_function_ops(capi, oracle, op):
     """ParallelPixelFunction(data, w, f)(Range(a, b)) — src/ParallelPixelFunction.cpp:12-17."""

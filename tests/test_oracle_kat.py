@@ -91,6 +91,22 @@ def test_mask_uses_float_cast(oracle):
     assert oracle.mask(u, invert=True).tolist() == [[1, 1, 1, 0, 1, 1]]
 
 
+def test_video_contour_kats(oracle):
+    """Frame contour rule (src/VideoWriterManager.cpp:60-74): round-half-even mask, cleared outer ring,
+    outer and hole borders of 8-connected components."""
+    u = np.zeros((9, 10)); u[2:7, 3:8] = 1; u[4, 5] = 0.4           # 5x5 square with a 1-pixel hole
+    c = oracle.video_contour(u)
+    ring = np.zeros((9, 10), dtype=np.uint8); ring[2:7, 3:8] = 1; ring[3:6, 4:7] = 0
+    ring[3, 5] = ring[5, 5] = ring[4, 4] = ring[4, 6] = 1           # the hole's 4-neighbours
+    assert np.array_equal(c, ring)
+    full = oracle.video_contour(np.full((5, 6), 3.0))               # object touching the frame: contour one pixel in
+    exp = np.zeros((5, 6), dtype=np.uint8); exp[1:4, 1:5] = 1; exp[2, 2:4] = 0
+    assert np.array_equal(full, exp)
+    half = np.full((5, 5), -1.0); half[2, 1:4] = [0.5, 1.5, 2.5]    # 0.5 -> 0, 1.5 -> 2, 2.5 -> 2
+    assert oracle.video_contour(half).tolist()[2] == [0, 0, 1, 1, 0]
+    assert oracle.video_contour(np.ones((2, 2))).sum() == 0         # nothing survives the cleared ring
+
+
 def test_region_means_simple(oracle):
     img = np.array([[10, 20], [30, 40]], dtype=np.uint8)
     u = np.zeros((2, 2))

@@ -1,0 +1,53 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for profiles/<name>/ on the GPU box:  tools/profile_round.sh <name>
+# (kernel-trace stats and PMC passes are separate runs; --pmc is never combined with trace domains)
+name=${1:-r01_final}
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/$name
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline"
+# 1. un-profiled bench line
+( cd $R && timeout -k 10 300 $CMD > $out/bench_default.json 2> $out/bench_default.err ) || echo "bench failed"
+# 2. kernel trace + stats
+rm -rf /tmp/kt
+( cd $R && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- $CMD > /tmp/kt.log 2>&1 ) || { echo "kernel-trace failed"; tail -5 /tmp/kt.log; }
+f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv
+# 3. PMC passes
+python3 - > $out/pmc_summary.json <<'PY'
+import json
+print("{}")
+PY
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64"; do
+  i=$((i+1)); rm -rf /tmp/pm_$i
+  ( cd $R && timeout -k 10 300 rocprofv3 --pmc $grp -d /tmp/pm_$i -o p --output-format csv -- python3 bench.py --steps 60 --warmup 40 --no-cpu-baseline > /tmp/pm_$i.log 2>&1 ) || { echo "pmc pass $i failed"; tail -3 /tmp/pm_$i.log; }
+  f=$(find /tmp/pm_$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 - "$f" "$out/pmc_summary.json" <<'PY'
+import csv, sys, json, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for r in rows:
+    kn = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+    a = acc[kn][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+d = json.load(open(sys.argv[2]))
+for kn, cs in acc.items():
+    for c, (v, n) in cs.items():
+        d.setdefault(kn, {})[c] = {"per_launch": v / n, "launches": n}
+json.dump(d, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+PY
+done
+python3 - $out <<'PY'
+import json, sys, csv
+o = sys.argv[1]
+b = json.loads(open(o + "/bench_default.json").read())
+print("bench avg launch us", b["roofline"]["avg_launch_us"], "frac", b["roofline"]["frac"])
+try:
+    for r in csv.DictReader(open(o + "/kernel_stats.csv")):
+        print("kernel_stats:", r["Name"][:90], "calls", r["Calls"], "avg ns", r["AverageNs"])
+except Exception as e: print("no kernel stats", e)
+d = json.load(open(o + "/pmc_summary.json"))
+for kn, cs in d.items():
+    if "wave" in kn:
+        print(kn[:60], {k: round(v["per_launch"], 1) for k, v in cs.items()})
+PY
