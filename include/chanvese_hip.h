@@ -87,12 +87,29 @@ const char *cvh_last_error(const cvh_context *ctx);
 /* Replaces the parameter block (may be called between runs). */
 int cvh_set_params(cvh_context *ctx, const cvh_params *p);
 
-/* Tuning / behaviour knobs, by name:
- *   "math_mode"  cvh_math_mode
- *   "finalize"   0 = region means reduced by the last-arriving workgroup inside the step
- *                kernel (default), 1 = by a separate one-workgroup kernel
- *   "trace"      capacity (iterations) of the per-iteration trace, 0 = off
- *   "sync_every" iterations enqueued between host polls of the stop flag (default 32) */
+/* Tuning / behaviour knobs, by name (defaults are what bench.py measures):
+ *   "math_mode"      cvh_math_mode
+ *   "finalize"       0 = region means reduced by the last-arriving workgroup inside the step
+ *                    kernel (default), 1 = by a separate one-workgroup kernel
+ *   "trace"          capacity (iterations) of the per-iteration trace, 0 = off
+ *   "sync_every"     iterations enqueued between host polls of the stop flag (default 32)
+ *   "graph"          1 = runs of 16 steps are replayed as one hipGraph (default), 0 = plain launches
+ *   "kernel"         data flow of the CSV step: -1 auto (= 2 below 2^28 pixels), 0 LDS tile,
+ *                    1 streaming strip (w % 16 == 0), 2 wave-streaming (default)
+ *   "tile_rows"      tile/strip kernels: rows per tile (0 auto, 12/14/16)
+ *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
+ *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
+ *   "dma"            tile kernel: 1 = global->LDS DMA loader (slower on MI355X, default 0)
+ *   wave kernel:  "wave_occupancy" waves per SIMD the grid is sized for (4 or 5, default 5),
+ *                 "wave_depth" rows per group (4 default, 8), "wave_prio" s_setprio progress
+ *                 equalisation (0 off, 1 quarters (default), 2-4 thresholds crowded to the end),
+ *                 "wave_sync" workgroup barrier per group (default 1), "wave_imgv" 16-byte image
+ *                 pieces (default 1), "wave_xcd" XCD-contiguous workgroup numbering (default 1),
+ *                 "wave_skew" per-mille strip-length skew (default 0), "wave_lds_cap",
+ *                 "wave_rev", "debug_times" (diagnostics)
+ *   "pm_kernel"      Perona-Malik data flow: 0 LDS tile, 1 wave-streaming (default)
+ *   "pm_strip_rows"  Perona-Malik wave kernel: rows per strip (0 auto)
+ * Unknown keys and out-of-range values return CVH_ERR_ARG. */
 int cvh_set_option(cvh_context *ctx, const char *key, long value);
 
 /* Uploads the C channel planes (what cv::split produced, src/main.cpp:934-937). */
