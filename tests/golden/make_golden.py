@@ -35,6 +35,7 @@ def csv_case(name, planes, u0, **pk):
         rec[f"trace_{s}"] = tr
     rec["stop_cond"] = np.array([O.stop_condition(planes, pk.get("tol", 1e-3))])
     rec["mask_10"] = O.mask(rec["u_10"])
+    rec["contour_10"] = O.video_contour(rec["u_10"])   # the video frame's contour map (src/VideoWriterManager.cpp:60-74)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
 
 
