@@ -86,7 +86,7 @@ def main():
 
     def run_steps(k):
         # interleave the images' streams in chunks so their kernels overlap on the GPU
-        chunk = 8
+        chunk = 8 if len(ctxs) > 1 else 16   # 16 = one hipGraph of the library (api.hip, kGraphSteps)
         done = 0
         while done < k:
             c = min(chunk, k - done)
