@@ -248,7 +248,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value != 0 && value != 12 && value != 14 && value != 16) return fail(c, CVH_ERR_ARG, "tile_rows must be 0 (auto), 12, 14 or 16");
     c->tile_rows = (int)value;
   } else if (!strcmp(key, "kernel")) {
-    if (value < -1 || value > 2) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile), 1 (strip) or 2 (wave)");
+    if (value < -1 || value > 3) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile), 1 (strip), 2 (wave) or 3 (wave, 2 pixels per lane)");
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
   } else if (!strcmp(key, "pm_kernel")) {
@@ -257,7 +257,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
     c->pm_strip_rows = (int)value;
   } else if (!strcmp(key, "wave_occupancy")) {
-    if (value < 4 || value > 5) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 4 or 5 (more waves per SIMD would spill registers)");
+    if (value < 3 || value > 5) return fail(c, CVH_ERR_ARG, "wave_occupancy must be 3..5 (more waves per SIMD would spill registers)");
     c->wave_minw = (int)value;
   } else if (!strcmp(key, "debug_times")) {
     // diagnostic: per-wave start/end stamps of the wave kernel, read back with cvh_debug_read
@@ -450,7 +450,28 @@ static Geometry resolve_geometry(const cvh_context *c)
   // default: the wave kernel (any width; fastest measured); it addresses the level set through
   // buffer instructions with 32-bit byte offsets and marks dropped lanes with offset 2^31, so
   // images of 2^28 pixels (2 GiB of level set) or more use the tile kernel
-  if ((c->kernel == 2 || c->kernel == -1) && c->n < ((size_t)1 << 28)) {
+  if ((c->kernel == 3 || c->kernel == -1) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 && c->n < ((size_t)1 << 28)) {
+    // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
+    // one round of resident waves (3 or 4 per SIMD)
+    g.strip = 3;
+    g.rows = 4;
+    g.tiles_x = (c->w + cvh_wave2_cols() - 1) / cvh_wave2_cols();
+    const int nbc = (g.tiles_x + 1) / 2;
+    int sr = c->strip_rows;
+    if (sr <= 0) {
+      const int occ = use_fast(c) ? (c->wave_minw >= 4 ? 4 : 3) : 2;
+      int nstrips = 2 * ((c->num_cus * occ) / nbc);
+      if (nstrips > 160) nstrips = 128;
+      if (nstrips < 1) nstrips = 1;
+      sr = (c->h + nstrips - 1) / nstrips;
+      if (sr < 8) sr = 8;
+    }
+    g.strip_rows = sr;
+    g.tiles_y = (c->h + sr - 1) / sr;
+    g.nblocks = nbc * ((g.tiles_y + 1) / 2);
+    return g;
+  }
+  if ((c->kernel == 2 || c->kernel == 3 || c->kernel == -1) && c->n < ((size_t)1 << 28)) {
     // wave kernel: 63 output columns per wave, strip_rows rows per wave, 4 waves per workgroup;
     // one round of resident waves (wave_minw per SIMD)
     g.strip = 2;
@@ -546,7 +567,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->stop_cond = c->stop_cond_h;
   a->npix = (double)c->n;
   for (int k = 0; k < CVH_MAX_CHANNELS; ++k) a->sum_img[k] = c->sum_img[k];
-  a->derive_complement = use_fast(c) ? (g.strip == 2 ? 2 : 1) : 0;  // 2: the wave kernel sums H - 1/2
+  a->derive_complement = use_fast(c) ? (g.strip >= 2 ? 2 : 1) : 0;  // 2: the wave kernels sum H - 1/2
   a->use_lut = c->use_lut;
   a->use_dma = c->use_dma;
 }
@@ -620,7 +641,8 @@ static int launch_one_step(cvh_context *c, int in_buf)
   CvhStepArgs a;
   fill_args(c, &a, in_buf);
   const int kind = resolve_geometry(c).strip;
-  if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
+  if (kind == 3) HIPCHK(c, cvh_launch_wave2(a, use_fast(c), c->stream));
+  else if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
   else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
   else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
   if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
@@ -659,7 +681,7 @@ static int enqueue_impl(cvh_context *c, int nsteps)
 {
   {
     const Geometry g = resolve_geometry(c);
-    if (g.strip == 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
+    if (g.strip >= 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
   }
   int s = 0;
   while (c->use_graph && nsteps - s >= kGraphSteps) {

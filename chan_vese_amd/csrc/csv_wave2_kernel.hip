@@ -1,0 +1,317 @@
+// csv_wave2_kernel.hip — wave-streaming CSV step with TWO pixels per lane (gfx950, wave64, 1 channel).
+//
+// Same arithmetic and the same data flow as csv_wave_kernel.hip (buffer loads/stores with dropped
+// lanes, next group parked in a per-wave LDS ring, branch-free interior groups), but a lane owns two
+// ADJACENT columns: a wave covers 128 columns (lane 0 holds the two west halo columns, lanes 1..63
+// produce 126 pixels per row).  Measured on MI355X: one vector-memory INSTRUCTION per
+// wave-row costs about as much whatever it moves, so 16-byte row loads/stores halve that cost per
+// pixel; the LDS exchange and the DPP move of the west neighbour's normalised gradient are halved
+// as well (one of the two x-neighbours of a pixel is in the same lane), the east halo is one column,
+// and the two pixels of a lane are independent dependency chains.
+//   ring slot (130 doubles): [a0 b0 a1 b1 ... a63 b63 | east extra]; per-lane read addresses implement
+//   the BORDER_REPLICATE clamps at the image's left / right edges, so the row values need no selects.
+// Workgroup = 2 wave-columns x 2 strips (a 4096-wide image has 33 wave-columns: pairs waste less than
+// quads).  Requires w % 16 == 0 and w >= 144 (16-byte image pieces); other shapes use kernel 2.
+#include "csv_device.h"
+#include "buffer_ops.h"
+#include "wave_math.h"
+#include <type_traits>
+
+using namespace cvh_dev;
+
+namespace {
+
+constexpr int W2 = 126;      // output columns per wave
+constexpr int XP2 = 130;     // ring slot pitch in doubles (129 used; 1040 bytes keeps 16-byte alignment)
+constexpr int R2 = 4;        // rows per group = ring slots
+constexpr int IMGP2 = 144;   // bytes per row of the per-wave image tile (9 x 16-byte pieces)
+constexpr int NS2 = cvh_nsums(1);
+
+template <bool FAST>
+struct Wave2Smem {
+  static constexpr int wave_doubles = R2 * XP2 + 64 + R2 * IMGP2 / 8;     // ring + scratch + image tile
+  static constexpr int off_x = 0;
+  static constexpr int off_red = off_x + 4 * wave_doubles;                // 4*NS
+  static constexpr int off_fin = off_red + 4 * NS2;                       // NS (+1 pad)
+  static constexpr int off_atan = off_fin + NS2 + 1;                      // FAST: CVH_ATAN2_N
+  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // FAST: 256 x {term, I}
+  static constexpr int off_flag = off_lut + (FAST ? 512 : 0);
+  static constexpr int doubles = off_flag + 2;
+  static constexpr size_t bytes = (size_t)doubles * sizeof(double);
+};
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+}
+
+template <bool FAST, int MINW>
+__global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhStepArgs a)
+{
+  using L = Wave2Smem<FAST>;
+  constexpr int NS = NS2, R = R2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *sred = smem + L::off_red;
+  double *sfin = smem + L::off_fin;
+  double *satan = smem + L::off_atan;
+  double *slut = smem + L::off_lut;
+  int *s_last = (int *)(smem + L::off_flag);
+
+  if (a.st->stopped) return;  // sticky stop: src/main.cpp:1000
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *xs = smem + L::off_x + wave * L::wave_doubles;
+  const int h = a.h, w = a.w;
+  if (tid == 0) *s_last = 0;
+
+  const double c1 = a.st->c1[0], c2 = a.st->c2[0], l1 = a.lambda1[0], l2 = a.lambda2[0];
+  const double eps = a.eps, eps2 = eps * eps;
+  const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_thr};
+
+  auto fill_tables = [&]() {
+    if (FAST) {
+      for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
+      const double v = (double)tid;
+      const double d1 = v - c1, d2 = v - c2;
+      const double reg = (d2 * d2) * l2 - (d1 * d1) * l1;
+      slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
+      slut[2 * tid + 1] = v;
+    }
+  };
+
+  double acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc[s] = 0;
+
+  // ---- this wave's strip: workgroup = 2 adjacent wave-columns x 2 adjacent strips
+  const int nwc = a.tiles_x, nstrips = a.tiles_y;
+  const int nbc = (nwc + 1) >> 1;
+  int bid = (int)blockIdx.x;
+  if (a.wave_xcd) {   // XCD-contiguous numbering (see csv_wave_kernel.hip)
+    const int nb = (int)gridDim.x, x = bid & 7, j = bid >> 3, q = nb >> 3, r = nb & 7;
+    bid = x * q + (x < r ? x : r) + j;
+  }
+  const int wc = (bid % nbc) * 2 + (wave & 1);
+  const int ws = (bid / nbc) * 2 + (wave >> 1);
+  const bool active = wc < nwc && ws < nstrips;
+  // the 4 waves of the workgroup meet at one barrier per group: all run the longer strip's group count
+  int wg_groups = 0;
+  {
+    const int wsa = (bid / nbc) * 2;
+    const int la = a.strip_bounds[wsa + 1] - a.strip_bounds[wsa];
+    const int lb = wsa + 1 < nstrips ? a.strip_bounds[wsa + 2] - a.strip_bounds[wsa + 1] : 0;
+    wg_groups = ((la > lb ? la : lb) + R - 1) / R;
+  }
+  int groups_done = 0;
+
+  if (active) {
+    const int s0 = a.strip_bounds[ws], s1 = a.strip_bounds[ws + 1];
+    const int c0 = W2 * wc - 2 + 2 * lane;                 // column of pixel `a`; pixel `b` is c0 + 1
+    const bool lane_valid = lane >= 1 && c0 < w;           // w is even: both pixels or none
+    const int cl = c0 < 0 ? 0 : (c0 > w - 2 ? w - 2 : c0); // even column of the 16-byte load
+    const double fxa = (c0 <= 0) ? 0.0 : 1.0;              // kappa_x(i,0) = 0 (:371); pixel b never is column 0
+    // per-lane ring indices: own pair, west neighbour of a, east neighbour of b (replicated at the image edges)
+    const int pa = 2 * lane;
+    const int pw = (lane == 0 || c0 <= 0) ? pa : pa - 1;   // lane 0 (halo) never uses its west value
+    const int pe = (c0 + 2 >= w) ? pa + 1 : pa + 2;        // lane 63 of a full wave: index 128 = the east extra
+    const double2_t *x_own = reinterpret_cast<const double2_t *>(xs + pa);
+    const double *x_w = xs + pw, *x_e = xs + pe;
+    double2_t *x_put = reinterpret_cast<double2_t *>(xs + pa);
+    // east extra: column 126 wc + 126 of R rows, one lane per row
+    const bool xlane = lane < R;
+    const int xrow = xlane ? lane : 0;
+    const int xcol = clampi(W2 * wc + W2, 0, w - 1);
+    double *x_ext = xlane ? xs + xrow * XP2 + 128 : xs + R * XP2 + lane;   // other lanes: scratch
+    const unsigned rowbytes = (unsigned)w * 8u, ubytes = (unsigned)h * rowbytes;
+    const unsigned voff_u = (unsigned)cl * 8u;
+    const unsigned voff_st = lane_valid ? (unsigned)c0 * 8u : kOobOffset;
+    const unsigned voff_x = ((unsigned)xrow * (unsigned)w + (unsigned)xcol) * 8u;
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u_in, ubytes);
+    const int ulast = s1 < h - 1 ? s1 : h - 1, ilast = s1 - 1;
+    auto U = [&](int r) -> double2_t { return buf_load_f64x2(ru, voff_u, (unsigned)clampi(r, 0, ulast) * rowbytes); };
+    auto UX = [&](int r0) -> double {
+      if (r0 + R - 1 <= ulast) return buf_load_f64(ru, voff_x, (unsigned)r0 * rowbytes);
+      return buf_load_f64(ru, ((unsigned)clampi(r0 + xrow, 0, ulast) * (unsigned)w + (unsigned)xcol) * 8u, 0u);
+    };
+    // image: 9 aligned 16-byte pieces per row, R rows by 9R lanes, staged in the per-wave tile
+    unsigned char *simg = reinterpret_cast<unsigned char *>(xs + R * XP2 + 64);
+    const int icol0 = (W2 * wc - 2) & ~15;                      // may be < 0
+    const int ipiece = lane % 9, irow = lane / 9;
+    const bool ilane = lane < 9 * R;
+    int ipc = icol0 + 16 * ipiece;
+    ipc = ipc < 0 ? 0 : (ipc > w - 16 ? w - 16 : ipc);
+    const unsigned voff_i = (unsigned)(ilane ? irow : 0) * (unsigned)w + (unsigned)ipc;
+    unsigned char *ipiece_dst = simg + irow * IMGP2 + ((icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0);
+    const int ibyte = cl - icol0;                               // bytes of (a, b): ibyte, ibyte + 1
+    const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[0], (unsigned)h * (unsigned)w);
+    auto IMQ = [&](int r0) -> u32x4_t {
+      if (r0 + R - 1 <= ilast) return buf_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w);
+      return buf_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, ilast) * (unsigned)w + (unsigned)ipc, 0u);
+    };
+    auto lds_fence = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    int im[R];   // the group's samples: byte of a | byte of b << 8
+    auto park = [&](const double2_t (&T)[R], double X, u32x4_t IQ) {
+      lds_fence();
+#pragma unroll
+      for (int j = 0; j < R; ++j) x_put[j * (XP2 / 2)] = T[j];
+      *x_ext = X;
+      if (ilane) *reinterpret_cast<u32x4_t *>(ipiece_dst) = IQ;
+      lds_fence();
+#pragma unroll
+      for (int k = 0; k < R; ++k) im[k] = (int)*reinterpret_cast<const unsigned short *>(simg + k * IMGP2 + ibyte);
+    };
+
+    // ---- prologue
+    const double2_t um2 = U(s0 - 2);
+    double2_t um = U(s0 - 1), u0 = U(s0);
+    double uw, ue;
+    {
+      double2_t T[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) T[j] = U(s0 + 1 + j);
+      const double X0 = UX(s0);
+      const double X = UX(s0 + 1);
+      const u32x4_t IQ = IMQ(s0);
+      fill_tables();
+      __syncthreads();
+      x_put[0] = u0;
+      if (xrow == 0) *x_ext = X0;
+      lds_fence();
+      uw = x_w[0]; ue = x_e[0];
+      park(T, X, IQ);
+    }
+    auto norm = [&](double fwd, double bwd, double c) -> double {
+      return FAST ? normalised4(fwd, bwd, c + c) : normalised<false>(fwd - c, central(bwd, fwd));
+    };
+    double nypa = norm(u0.x, um2.x, um.x), nypb = norm(u0.y, um2.y, um.y);   // ny at row s0-1
+    if (s0 == 0) {   // kappa_y(0, .) = 0 (:372): ny_prev := row 0's own ny (see csv_wave_kernel.hip)
+      const double2_t up0 = x_own[0];
+      nypa = norm(up0.x, um.x, u0.x); nypb = norm(up0.y, um.y, u0.y);
+    }
+
+    // update of one pixel from its 4 neighbours, its x-gradient nx and the west neighbour's (nxl)
+    auto pixel = [&](double c, double n_, double s_, double nx, double nxl, double fx, double &nyp, int byte,
+                     double &ud_out, double &Ik_out) -> double {
+      const double ny = norm(s_, n_, c);
+      double kappa, ud, Ik;
+      if (FAST) {
+        kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
+        const double2_t e = reinterpret_cast<const double2_t *>(slut)[byte];
+        Ik = e.y;
+        ud = __builtin_fma(kappa, a.alpha, e.x);                       // :985
+        const double qd = __builtin_fma(c, c, eps2) * a.dk1;           // 1/delta_eps(u)
+        const double r0 = __builtin_amdgcn_rcp(qd);
+        const double er = __builtin_fma(-qd, r0, 1.0);
+        ud = ud * __builtin_fma(__builtin_fma(er, er, er), r0, r0);    // :992
+      } else {
+        const double kx = (fx == 0.0) ? 0.0 : nx - nxl;                // :371
+        const double ky = ny - nyp;                                    // :372
+        kappa = kx + ky;                                               // :373
+        Ik = (double)byte;
+        const double d1 = Ik - c1, d2 = Ik - c2;
+        const double vin = (d1 * d1) * l1, vout = (d2 * d2) * l2;      // :307-310
+        ud = 0.0;                                                      // :965
+        ud += vout - vin;                                              // :979
+        ud = kappa * a.alpha + ud * a.beta + a.gamma;                  // :985
+        ud = ud * (eps / (kPi * (eps2 + c * c)));                      // :209, :992
+      }
+      nyp = ny;
+      ud_out = ud; Ik_out = Ik;
+      return c + ud;                                                   // :994
+    };
+
+    auto row = [&](int i, int k, bool live) {
+      const double2_t up = x_own[k * (XP2 / 2)];
+      const double uw_n = x_w[k * XP2], ue_n = x_e[k * XP2];
+      const int ba = im[k] & 0xff, bb = (im[k] >> 8) & 0xff;
+      // x-gradients first: nx(b) is the west gradient of lane+1's a (DPP), nx(a) the west gradient of b
+      const double nxa = norm(u0.y, uw, u0.x);       // east = own b, west = lane-1's b
+      const double nxb = norm(ue, u0.x, u0.y);       // east = lane+1's a, west = own a
+      const double nxla = dpp_from_left(nxb);
+      double uda, udb, Ia, Ib, nya = nypa, nyb = nypb;
+      const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nya, ba, uda, Ia);
+      const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, bb, udb, Ib);
+      double hva, hvb;
+      if (FAST) {   // far/near decided per WAVE for both pixels (uniform branch)
+        if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {
+          hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
+        } else {
+          hva = heaviside_centred_near(va, a.inv_eps, satan); hvb = heaviside_centred_near(vb, a.inv_eps, satan);
+        }
+      } else {
+        hva = heaviside_strict(va, eps); hvb = heaviside_strict(vb, eps);
+      }
+      buf_store_f64x2(double2_t{va, vb}, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+      if (live) {
+        if (FAST) {
+          acc[0] += hva; acc[0] += hvb;
+          acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
+          acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
+        } else {
+          acc[0] += hva; acc[1] += (1 - hva); acc[2] += Ia * hva; acc[3] += Ia * (1 - hva); acc[4] += uda * uda;
+          acc[0] += hvb; acc[1] += (1 - hvb); acc[2] += Ib * hvb; acc[3] += Ib * (1 - hvb); acc[4] += udb * udb;
+        }
+        nypa = nya; nypb = nyb;
+      }
+      um = u0; u0 = up;
+      uw = uw_n; ue = ue_n;
+    };
+
+    auto group = [&](int ib, auto interior_tag) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
+      if (a.wave_sync) { __builtin_amdgcn_s_barrier(); ++groups_done; }
+      double2_t T[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64x2(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
+      const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
+      const u32x4_t IQ = INTERIOR ? buf_load_b128(ri, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
+#pragma unroll
+      for (int k = 0; k < R; ++k) row(ib + k, k, INTERIOR ? true : (ib + k) < s1);
+      park(T, X, IQ);
+    };
+    int ib = s0;
+    for (; ib + 2 * R <= ulast; ib += R) group(ib, std::true_type{});
+    for (; ib < s1; ib += R) group(ib, std::false_type{});
+    const double vmask = lane_valid ? 1.0 : 0.0;   // exact: halo / out-of-image lanes contribute nothing
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;
+  } else {
+    fill_tables();
+    __syncthreads();
+  }
+  if (a.wave_sync) {   // remaining barriers of the workgroup (shorter strip, idle wave)
+    for (; groups_done < wg_groups; ++groups_done) __builtin_amdgcn_s_barrier();
+  }
+  const double total = block_reduce<NS>(acc, sred);
+  publish_partials_and_maybe_finalize<1>(a, total, sred, sfin, s_last, gridDim.x);
+}
+
+template <bool FAST, int MINW>
+hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
+{
+  using L = Wave2Smem<FAST>;
+  static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
+  hipLaunchKernelGGL((csv_wave2_kernel<FAST, MINW>), dim3(a.nparts), dim3(CVH_BLOCK), L::bytes, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int cvh_wave2_cols() { return W2; }
+
+hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s)
+{
+  if (!fast) return launch_wave2<false, 2>(a, s);
+  return a.wave_minw >= 4 ? launch_wave2<true, 4>(a, s) : launch_wave2<true, 3>(a, s);
+}

@@ -90,6 +90,8 @@ void cvh_step_grid(int h, int w, int tile_rows, int *tiles_x, int *tiles_y);
 int cvh_step_max_blocks(int h, int w);
 hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
+int cvh_wave2_cols();
+hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s);
 hipError_t cvh_launch_wave(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave_cols();
 hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,

@@ -76,7 +76,9 @@ def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize, kernel):
                                   dict(kernel=1, tile_rows=12), dict(kernel=1, tile_rows=16),
                                   dict(kernel=2), dict(kernel=2, strip_rows=8, lut=0),
                                   dict(kernel=2, strip_rows=52, wave_occupancy=4),
-                                  dict(kernel=2, strip_rows=1000, wave_skew=150, wave_prio=2)])
+                                  dict(kernel=2, strip_rows=1000, wave_skew=150, wave_prio=2),
+                                  dict(kernel=3), dict(kernel=3, strip_rows=8), dict(kernel=3, strip_rows=37, wave_occupancy=4),
+                                  dict(kernel=3, strip_rows=1000, wave_xcd=0)])
 def test_csv_kernel_variants(capi, oracle, mode, math, opts):
     """Every data-flow variant of the step kernel (LDS tile / streaming strip, ring chunking,
     ragged last chunk, LDS-DMA loader, LUT on/off) against the oracle on a multi-tile image."""

@@ -14,7 +14,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in rows:
-    if "csv_wave_kernel" in r["Kernel_Name"]:
+    if "csv_wave" in r["Kernel_Name"]:
         k = r["Counter_Name"]; acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 for k, (v, n) in acc.items():
     print("%-28s per-launch %.6g  (launches %d)" % (k, v / n, n))
