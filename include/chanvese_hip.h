@@ -94,13 +94,14 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "trace"          capacity (iterations) of the per-iteration trace, 0 = off
  *   "sync_every"     iterations enqueued between host polls of the stop flag (default 32)
  *   "graph"          1 = runs of 16 steps are replayed as one hipGraph (default), 0 = plain launches
- *   "kernel"         data flow of the CSV step: -1 auto (= 2 below 2^28 pixels), 0 LDS tile,
- *                    1 streaming strip (w % 16 == 0), 2 wave-streaming (default)
+ *   "kernel"         data flow of the CSV step: -1 auto (3 where it applies, else 2; 0 from 2^28 pixels),
+ *                    0 LDS tile, 1 streaming strip (w % 16 == 0), 2 wave-streaming, 3 wave-streaming with
+ *                    2 pixels per lane (1 channel, w % 16 == 0, w >= 144; other shapes fall back to 2)
  *   "tile_rows"      tile/strip kernels: rows per tile (0 auto, 12/14/16)
  *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
  *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
  *   "dma"            tile kernel: 1 = global->LDS DMA loader (slower on MI355X, default 0)
- *   wave kernel:  "wave_occupancy" waves per SIMD the grid is sized for (4 or 5, default 5),
+ *   wave kernel:  "wave_occupancy" waves per SIMD the grid is sized for (3..5, default 5; kernel 3: 4),
  *                 "wave_depth" rows per group (4 default, 8), "wave_prio" s_setprio progress
  *                 equalisation (0 off, 1 quarters (default), 2-4 thresholds crowded to the end),
  *                 "wave_sync" workgroup barrier per group (default 1), "wave_imgv" 16-byte image
