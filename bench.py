@@ -139,7 +139,7 @@ def main():
         workload = (f"{n}x{n} {C}-channel synthetic disk, checkerboard init, {args.steps} CSV iterations, tol 0"
                     + (" (BASELINE configs[1])" if (n, C, args.steps, total_images) == (4096, 1, 500, 1) else ""))
         kopt = dict(kv.split("=") for kv in (args.opt or [])).get("kernel", "-1")
-        two_px = C == 1 and n % 16 == 0 and n >= 144 and kopt in ("-1", "3")   # api.hip resolve_geometry
+        two_px = C == 1 and n % 16 == 0 and n >= 144 and (kopt == "3" or (kopt == "-1" and n * n <= 40000000))   # api.hip resolve_geometry
         kernel_name = {"0": "csv_step_kernel (tile)", "1": "csv_strip_kernel"}.get(kopt, "csv_wave2_kernel" if two_px else "csv_wave_kernel")
         out = {
             "metric": "Mpixel-iterations/s (CSV u-update)",

@@ -450,7 +450,10 @@ static Geometry resolve_geometry(const cvh_context *c)
   // default: the wave kernel (any width; fastest measured); it addresses the level set through
   // buffer instructions with 32-bit byte offsets and marks dropped lanes with offset 2^31, so
   // images of 2^28 pixels (2 GiB of level set) or more use the tile kernel
-  if ((c->kernel == 3 || c->kernel == -1) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 && c->n < ((size_t)1 << 28)) {
+  // auto: the 2-pixel kernel up to ~6144^2 (measured ahead of the 1-pixel kernel at 512^2 .. 5120^2, level at 6144^2,
+  // 4 % behind at 8192^2, tools/size_sweep.sh)
+  if ((c->kernel == 3 || (c->kernel == -1 && c->n <= (size_t)40000000)) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 &&
+      c->n < ((size_t)1 << 28)) {
     // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
     // one round of resident waves (3 or 4 per SIMD)
     g.strip = 3;
