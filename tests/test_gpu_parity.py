@@ -68,6 +68,24 @@ def test_csv_small_shapes(capi, oracle, shape, mode, math, finalize, kernel):
 
 
 @pytest.mark.parametrize("mode,math", MODES)
+@pytest.mark.parametrize("shape", [(1, 144), (2, 160), (3, 256), (5, 2016), (9, 272), (40, 144), (17, 1008), (8, 4096)])
+def test_csv_two_pixel_kernel_edge_shapes(capi, oracle, shape, mode, math):
+    """csv_wave2_kernel (2 pixels per lane, w % 16 == 0, w >= 144): one-row images, a single wave-column, widths that are
+    exact multiples of its 126-column stride (full last wave), a partial last wave, strips shorter than a group."""
+    h, w = shape
+    rng = np.random.default_rng(h * 104729 + w)
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    u0 = oracle.checkerboard(h, w) if h > 2 else rng.normal(size=shape)
+    for steps, opts in ((1, dict(kernel=3)), (4, dict(kernel=3, strip_rows=8)), (9, dict(kernel=3, wave_occupancy=3, wave_xcd=0))):
+        u_c, done_c, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(tol=0), steps)
+        u_g, done_g, nrm_g, tr_g, m_g = gpu_run(capi, [img], u0, steps, math, opts=opts, tol=0)
+        assert done_g == done_c == steps
+        assert rel_err(u_g, u_c) <= 1e-9, (steps, rel_err(u_g, u_c))
+        assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+        assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+@pytest.mark.parametrize("mode,math", MODES)
 @pytest.mark.parametrize("opts", [dict(kernel=0, tile_rows=14), dict(kernel=0, tile_rows=16, lut=0),
                                   dict(kernel=0, tile_rows=14, dma=1),
                                   dict(kernel=1, tile_rows=16, strip_rows=16),
