@@ -67,6 +67,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long t_start = a.dbg_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
   double *xs = smem + L::off_x + wave * L::wave_doubles;
   const int h = a.h, w = a.w;
   if (tid == 0) *s_last = 0;
@@ -268,9 +269,30 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       uw = uw_n; ue = ue_n;
     };
 
+    int prio = 3;
+    if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
     auto group = [&](int ib, auto interior_tag) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
       if (a.wave_sync) { __builtin_amdgcn_s_barrier(); ++groups_done; }
+      if (a.wave_prio) {
+        // At equal priority the SIMD arbiter serves its OLDEST wave first: the 4 waves of a SIMD then run almost
+        // one after the other (measured: they finish 11 us apart, the last one alone on the SIMD).  Waves that
+        // are AHEAD lower their priority, so all finish together and hide each other's latencies to the end.
+        const int rem = s1 - ib, len = s1 - s0;
+        int pq;
+        if (a.wave_prio == 1) pq = (rem * 4 - 1) / len;  // 3,2,1,0 by quarters of the strip
+        else {
+          const int sh = a.wave_prio == 4 ? 1 : a.wave_prio;  // 2: 1/4,1/8,1/16 of the strip left; 3: 1/2,1/4,1/8; 4: 1/8,1/16,1/32
+          pq = (rem << (4 - sh)) > len ? 3 : ((rem << (5 - sh)) > len ? 2 : ((rem << (6 - sh)) > len ? 1 : 0));
+        }
+        if (pq != prio) {
+          prio = pq;
+          if (pq >= 3) __builtin_amdgcn_s_setprio(3);
+          else if (pq == 2) __builtin_amdgcn_s_setprio(2);
+          else if (pq == 1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
       double2_t T[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64x2(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
@@ -293,8 +315,19 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   if (a.wave_sync) {   // remaining barriers of the workgroup (shorter strip, idle wave)
     for (; groups_done < wg_groups; ++groups_done) __builtin_amdgcn_s_barrier();
   }
+  if (a.dbg_times && lane == 0) {  // diagnostic stamps (tools/wave_timeline.py): only ever written to their own buffer
+    unsigned long long *d = a.dbg_times + (size_t)(blockIdx.x * 4 + wave) * 4;
+    d[0] = t_start;
+    d[1] = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    d[2] = hwid;
+    d[3] = xcc;
+  }
   const double total = block_reduce<NS>(acc, sred);
   publish_partials_and_maybe_finalize<1>(a, total, sred, sfin, s_last, gridDim.x);
+  if (a.dbg_times && tid == 0) a.dbg_times[(size_t)gridDim.x * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <bool FAST, int MINW>

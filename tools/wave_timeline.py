@@ -5,7 +5,7 @@ import numpy as np
 from chan_vese_amd import capi, synth
 n = int(__import__("os").environ.get("N", "4096"))
 ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
-ctx.set_option("kernel", 2)
+ctx.set_option("kernel", int(__import__("os").environ.get("KERNEL", "2")))
 for kv in sys.argv[1:]:
     k, v = kv.split("="); ctx.set_option(k, int(v))
 ctx.set_option("debug_times", 1)
