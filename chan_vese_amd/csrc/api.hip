@@ -462,7 +462,7 @@ static Geometry resolve_geometry(const cvh_context *c)
     const int nbc = (g.tiles_x + 1) / 2;
     int sr = c->strip_rows;
     if (sr <= 0) {
-      const int occ = use_fast(c) ? (c->wave_minw >= 4 ? 4 : 3) : 2;
+      const int occ = use_fast(c) ? (c->wave_minw == 4 ? 4 : 3) : 2;   // as compiled: cvh_launch_wave2
       int nstrips = 2 * ((c->num_cus * occ) / nbc);
       if (nstrips > 160) nstrips = 128;
       if (nstrips < 1) nstrips = 1;

@@ -232,6 +232,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       return c + ud;                                                   // :994
     };
 
+    // DEFER (3 waves/SIMD: register room): rows without a branch, see csv_wave_kernel.hip
+    constexpr bool DEFER = FAST && MINW <= 3;
+    double2_t keep[R];
+    unsigned long long near_mask[R];
     auto row = [&](int i, int k, bool live) {
       const double2_t up = x_own[k * (XP2 / 2)];
       const double uw_n = x_w[k * XP2], ue_n = x_e[k * XP2];
@@ -244,7 +248,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nya, ba, uda, Ia);
       const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, bb, udb, Ib);
       double hva, hvb;
-      if (FAST) {   // far/near decided per WAVE for both pixels (uniform branch)
+      if (FAST && DEFER) {   // far-field form on every lane; near lanes are corrected once per group (no branch in a row)
+        hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
+        keep[k] = double2_t{va, vb};
+        near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
+      } else if (FAST) {   // far/near decided per WAVE for both pixels (uniform branch)
         if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {
           hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
         } else {
@@ -300,6 +308,19 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       const u32x4_t IQ = INTERIOR ? buf_load_b128(ri, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
 #pragma unroll
       for (int k = 0; k < R; ++k) row(ib + k, k, INTERIOR ? true : (ib + k) < s1);
+      if (DEFER && (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          if (near_mask[k] != 0ull && (INTERIOR || (ib + k) < s1)) {
+            const double xa = keep[k].x, xb = keep[k].y;
+            const double da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
+            const double db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
+            acc[0] += da; acc[0] += db;
+            acc[2] = __builtin_fma((double)(im[k] & 0xff), da, acc[2]);
+            acc[2] = __builtin_fma((double)((im[k] >> 8) & 0xff), db, acc[2]);
+          }
+        }
+      }
       park(T, X, IQ);
     };
     int ib = s0;
@@ -346,5 +367,6 @@ int cvh_wave2_cols() { return W2; }
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s)
 {
   if (!fast) return launch_wave2<false, 2>(a, s);
-  return a.wave_minw >= 4 ? launch_wave2<true, 4>(a, s) : launch_wave2<true, 3>(a, s);
+  // default: 3 waves/SIMD with branch-free rows (measured 65.1 vs 66.3 us for 4 waves/SIMD with the per-row branch)
+  return a.wave_minw == 4 ? launch_wave2<true, 4>(a, s) : launch_wave2<true, 3>(a, s);
 }
