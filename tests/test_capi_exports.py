@@ -28,6 +28,25 @@ def test_header_symbols_are_exported(built):
     assert declared == set(built.EXPORTS), declared ^ set(built.EXPORTS)
 
 
+def test_header_is_plain_c(built, tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 and a C program links against the library by symbol."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "chanvese_hip.h"\n#include <stdio.h>\n'
+        "int main(void) { cvh_params p; cvh_default_params(&p); int n = -1; cvh_device_count(&n);\n"
+        '  printf("%s %g %g %d\\n", cvh_version(), p.mu, p.dt, cvh_pm_trip_count(0.25, 20)); return n < 0; }\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(built.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lchanvese_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "gfx950" in out.stdout and " 0.5 1 80" in out.stdout
+
+
 def test_version_and_defaults(built):
     assert b"gfx950" in built.lib().cvh_version()
     p = built.make_params()
