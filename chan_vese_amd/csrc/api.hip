@@ -35,7 +35,7 @@ struct cvh_context {
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
   int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
-  int pm_kernel = 1;    // 0 tile kernel, 1 wave kernel
+  int pm_kernel = -1;   // -1 auto, 0 tile kernel, 1 wave kernel, 2 wave kernel with 2 pixels per lane
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = 1, wave_imgv = 1, wave_depth = 4;
   double *d_dummy = nullptr;
@@ -252,7 +252,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
   } else if (!strcmp(key, "pm_kernel")) {
-    c->pm_kernel = value != 0;
+    if (value < -1 || value > 2) return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave) or 2 (wave, 2 pixels per lane)");
+    c->pm_kernel = (int)value;
   } else if (!strcmp(key, "pm_strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
     c->pm_strip_rows = (int)value;
@@ -899,8 +900,24 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   memset(&a, 0, sizeof(a));
   a.h = c->h; a.w = c->w; a.K2 = K * K; a.L = L;
   a.invK2 = 1.0 / (K * K); a.L4 = L / 4; a.fast = use_fast(c) ? 1 : 0;
-  const bool pm_wave = c->pm_kernel == 1;
-  if (pm_wave) {
+  // auto: the 2-pixel kernel for large planes (measured 50.4 vs 53.3 us/step at 4096^2, but 19 vs 15.7 at 2048^2:
+  // its strips get too short there), the 1-pixel wave kernel otherwise
+  const bool pm2_ok = c->w % 2 == 0 && c->w >= 128 && c->n < ((size_t)1 << 28);
+  const bool pm_wave2 = pm2_ok && (c->pm_kernel == 2 || (c->pm_kernel == -1 && c->n >= (size_t)12000000));
+  const bool pm_wave = !pm_wave2 && c->pm_kernel != 0;
+  if (pm_wave2) {   // 2 pixels per lane: 124 output columns per wave, workgroup = 2 wave-columns x 2 strips
+    a.tiles_x = (c->w + cvh_pm_wave2_cols() - 1) / cvh_pm_wave2_cols();
+    int sr = c->pm_strip_rows;
+    if (sr <= 0) {
+      const int nbc = (a.tiles_x + 1) / 2;
+      int nstrips = 2 * ((c->num_cus * 3) / nbc);   // ~3 waves per SIMD resident
+      if (nstrips < 1) nstrips = 1;
+      sr = (c->h + nstrips - 1) / nstrips;
+      sr = ((sr + 3) / 4) * 4;
+      if (sr < 8) sr = 8;
+    }
+    a.strip_rows = sr;
+  } else if (pm_wave) {
     a.tiles_x = (c->w + cvh_pm_wave_cols() - 1) / cvh_pm_wave_cols();
     int sr = c->pm_strip_rows;
     if (sr <= 0) {  // ~3 waves per SIMD resident
@@ -921,7 +938,8 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
       int cur = 0;
       for (int t = 0; t < trips; ++t) {
         a.in = c->d_pm[cur]; a.out = c->d_pm[cur ^ 1];
-        if (pm_wave) HIPCHK(c, cvh_launch_pm_wave(a, c->stream));
+        if (pm_wave2) HIPCHK(c, cvh_launch_pm_wave2(a, c->stream));
+        else if (pm_wave) HIPCHK(c, cvh_launch_pm_wave(a, c->stream));
         else HIPCHK(c, cvh_launch_pm_step(a, c->stream));
         cur ^= 1;
       }

@@ -101,6 +101,8 @@ int cvh_init_sum_blocks(int h, int w);
 
 hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hipStream_t s);
 hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s);
+int cvh_pm_wave2_cols();
+hipError_t cvh_launch_pm_wave2(const CvhPmArgs &a, hipStream_t s);
 hipError_t cvh_launch_pm_wave(const CvhPmArgs &a, hipStream_t s);
 int cvh_pm_wave_cols();
 hipError_t cvh_launch_pm_store(const double *state, uint8_t *plane, size_t n, hipStream_t s);
