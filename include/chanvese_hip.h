@@ -108,7 +108,8 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *                 pieces (default 1), "wave_xcd" XCD-contiguous workgroup numbering (default 1),
  *                 "wave_skew" per-mille strip-length skew (default 0), "wave_lds_cap",
  *                 "wave_rev", "debug_times" (diagnostics)
- *   "pm_kernel"      Perona-Malik data flow: 0 LDS tile, 1 wave-streaming (default)
+ *   "pm_kernel"      Perona-Malik data flow: -1 auto (2 from 12 Mpixel planes on, else 1), 0 LDS tile,
+ *                    1 wave-streaming, 2 wave-streaming with 2 pixels per lane (even w >= 128)
  *   "pm_strip_rows"  Perona-Malik wave kernel: rows per strip (0 auto)
  * Unknown keys and out-of-range values return CVH_ERR_ARG. */
 int cvh_set_option(cvh_context *ctx, const char *key, long value);
