@@ -11,4 +11,9 @@ done = 0
 for batch in [16] * 8 + [64] * 4 + [128] * 2:
     ctx.enqueue_steps(batch); ctx.sync()
     done += batch
-    print("iterations %4d..%4d: %.2f us/iter" % (done - batch, done, ctx.last_run_ms() * 1e3 / batch))
+    ms = ctx.last_run_ms()
+    u = ctx.get_levelset()
+    import numpy as np
+    a_ = np.abs(u)
+    rows_near = (a_.reshape(n, -1, 128).min(axis=2) < 64).mean()   # share of 128-column row segments holding a near-field pixel
+    print("iterations %4d..%4d: %.2f us/iter   |u|<64: %.5f of pixels, %.4f of 128-px row segments; |u| median %.0f max %.0f" % (done - batch, done, ms * 1e3 / batch, (a_ < 64).mean(), rows_near, np.median(a_), a_.max()))
