@@ -32,7 +32,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=100)   # untimed; the first ~100 launches of a cold process run slower (clock ramp)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3])
     ap.add_argument("--images-per-gpu", type=int, default=1)
