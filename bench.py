@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """bench.py — Mpixel-iterations/s of the fused CSV level-set update on MI355X.
 
-A "step" is one pass of the hot path over the resident batch: one CSV iteration
-(curvature + region terms + delta map + update + the c1/c2 sums) of every image this rank
-holds.  N=1 runs BASELINE.json configs[1] (4096x4096, 1 channel, checkerboard init,
-500 iterations, tol 0 so exactly K iterations execute); N>1 shards independent images, one
-process per GPU, `--images-per-gpu` each (weak scaling: per-GPU work fixed), no data-path
-collective — torch.distributed (RCCL) is used only for the barriers and the max-over-ranks
-of the elapsed time.  Inputs (image planes, level set) are resident in HBM before the timed
-region starts.
+A "step" is one pass of the hot path over the resident batch: one CSV iteration (curvature +
+region terms + delta map + update + the c1/c2 sums) of every image this rank holds.
 
-Prints ONE JSON line on rank 0 (see the driver's contract) with two extra objects:
-  roofline      algorithmic bytes (2*8 + C bytes per pixel-iteration) per launch
-                / average launch duration from HIP events on the kernel's stream
-  cpu_baseline  the CPU oracle (reference-faithful pass structure, oracle/cv_oracle.c) timed
-                on this host's cores on a bounded sample of the same workload (rank 0, N=1)
+Workloads (`--config`, BASELINE.json `configs`):
+  C2 (default at N=1)  4096x4096, 1 channel, clean disk, checkerboard init, 500 iterations, tol 0
+  C3                   4096x4096, 3 channels (per-channel lambda), 300 iterations
+  C4                   2048x2048 noisy disk: Perona-Malik 1000 steps (K=30, L=0.25, T=250) timed as its
+                       own phase (`pm` object, 16 B per plane-pixel-step), then 200 CSV iterations
+  C5 (default at N>1)  the per-GPU share of the 64-image batch: 8 noisy 4096x4096 images per GPU
+                       (images 8r..8r+7 on rank r), interleaved on their own streams
+  C4-image, C5-image   one C4 / C5 image (noise 32 at 2048^2 / noise 16 at 4096^2), CSV only
+`--gpus N` (N>1) without a launcher (WORLD_SIZE unset) starts N child ranks itself — fresh processes,
+one per GPU, before this process touches the GPU — and relays rank 0's line.  Under
+`python -m torch.distributed.run` the ranks are used as launched.  There is no data-path collective:
+torch.distributed (RCCL) carries the barriers, the max-over-ranks of the elapsed time and the end-of-run
+gather of per-rank records.  Inputs (image planes, level set) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (the driver's contract) with extra objects:
+  roofline      algorithmic bytes ((2*8 + C) per pixel-iteration) per launch / average launch
+                duration from HIP events on the kernel's stream
+  cpu_baseline  the CPU oracle (reference-faithful pass structure, oracle/cv_oracle.c) on this host's
+                cores, bounded sample of the same workload (rank 0, N=1)
+  phases        (N=1) us per iteration over iterations 1-16 / 17-100 / 101-500 of a fresh run from the
+                checkerboard, one sync per segment, measured after the timed region
+  pm            (C4) the Perona-Malik phase with its own roofline
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,62 +40,139 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
+CONFIGS = {
+    #            n     C  images  steps  description
+    "C2":       (4096, 1, 1, 500, "clean disk (BASELINE configs[1])"),
+    "C3":       (4096, 3, 1, 300, "3-channel disks, lambda1 1 1 0.5, lambda2 1 0.5 1 (BASELINE configs[2])"),
+    "C4":       (2048, 1, 1, 200, "noisy disk (noise 32, seed 1) after Perona-Malik 1000 steps K=30 L=0.25 (BASELINE configs[3])"),
+    "C5":       (4096, 1, 8, 500, "per-GPU share of the 64-image batch: noisy disks (noise 16, seed 1000+b) (BASELINE configs[4])"),
+    "C4-image": (2048, 1, 1, 200, "noisy disk (noise 32, seed 1), no Perona-Malik"),
+    "C5-image": (4096, 1, 1, 500, "noisy disk (noise 16, seed 1000), image 0 of the batch"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=100)   # untimed; the first ~100 launches of a cold process run slower (clock ramp)
-    ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--channels", type=int, default=1, choices=[1, 3])
-    ap.add_argument("--images-per-gpu", type=int, default=1)
-    ap.add_argument("--math", default="default", choices=["default", "strict", "fast"])
+    ap.add_argument("--steps", type=int, default=None, help="timed iterations (default: the config's count)")
+    ap.add_argument("--warmup", type=int, default=100)   # untimed iterations on the same level set
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS))
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--channels", type=int, default=None, choices=[1, 3])
+    ap.add_argument("--images-per-gpu", type=int, default=None)
+    ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--finalize", type=int, default=0, choices=[0, 1])
     ap.add_argument("--opt", action="append", default=[], help="context option key=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phases", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
-    return ap.parse_args()
+    ap.add_argument("--pm-steps", type=int, default=1000, help="C4: Perona-Malik steps (T = steps * 0.25)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` started directly: N child ranks, one per GPU, created BEFORE this process makes
+    any HIP / torch.cuda call (the parent never touches the GPU and never re-execs itself).  Rank 0's
+    stdout (the JSON line) is relayed; the exit code is the worst child's."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def resolve_workload(args, world):
+    name = args.config or ("C2" if world == 1 else "C5")
+    n, C, images, steps, desc = CONFIGS[name]
+    n = args.size or n
+    C = args.channels or C
+    if args.channels == 3 and args.config is None:
+        name, desc = "C3", CONFIGS["C3"][4]
+    images = args.images_per_gpu or images
+    steps = steps if args.steps is None else args.steps
+    return name, n, C, images, steps, desc
+
+
+def image_planes(name, n, gb):
+    from chan_vese_amd import synth
+    if name == "C3":
+        return synth.config_planes("C3", n)
+    if name in ("C4", "C4-image"):
+        return synth.config_planes("C4", n)
+    if name in ("C5", "C5-image"):
+        return [synth.batch_image(gb, n)]
+    return synth.config_planes("C2", n)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     from chan_vese_amd import batch
-    # torch (if any) is imported inside init_distributed, BEFORE the HIP library is loaded, so
-    # that both share torch's bundled HIP runtime.  CHANVESE_DIST_BACKEND=gloo rehearses the
-    # multi-rank path on one GPU (all ranks on device 0).
+    # torch (if any) is imported inside init_distributed, BEFORE the HIP library is loaded, so that both
+    # share torch's bundled HIP runtime.  CHANVESE_DIST_BACKEND=gloo rehearses the multi-rank path on
+    # one GPU (all ranks on device 0); CHANVESE_BENCH_DRYRUN=1 additionally skips the GPU work (CPU test
+    # of the launch / gather / report path; its line says "data": "dry-run" and measures nothing).
     dist, rank, world, local_rank = batch.init_distributed(os.environ.get("CHANVESE_DIST_BACKEND"))
+    dry = os.environ.get("CHANVESE_BENCH_DRYRUN") == "1"
     torch = None
     if dist is not None and dist.get_backend() == "nccl":
         import torch
 
-    import numpy as np
-    from chan_vese_amd import capi, synth
-
-    n, C = args.size, args.channels
-    device = local_rank % max(capi.device_count(), 1)
-    math_mode = {"default": 0, "strict": 1, "fast": 2}[args.math]
-
-    # ---- resident inputs: image b of this rank, checkerboard level set
+    name, n, C, images, steps, desc = resolve_workload(args, world)
+    math_mode = {"strict": 1, "fast": 2}[args.math]
+    pm_info = None
+    phases = None
     ctxs = []
-    u0 = capi.checkerboard_host(n, n)
-    for b in range(args.images_per_gpu):
-        gb = rank * args.images_per_gpu + b
-        if world == 1 and args.images_per_gpu == 1:
-            planes = synth.config_planes("C2" if C == 1 else "C3", n)
-        elif C == 1:
-            planes = [synth.batch_image(gb, n)]
-        else:
-            planes = synth.config_planes("C3", n)
-        p = capi.make_params(tol=0.0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]) if C == 3 else capi.make_params(tol=0.0)
-        ctx = capi.Context(n, n, C, p, device=device)
-        ctx.set_option("math_mode", math_mode)
-        ctx.set_option("finalize", args.finalize)
-        for kv in args.opt:
-            k, v = kv.split("=")
-            ctx.set_option(k, int(v))
-        ctx.set_image(planes)
-        ctx.set_levelset(u0)
-        ctxs.append(ctx)
+    kernel_ms = [0.0]
+
+    if not dry:
+        from chan_vese_amd import capi
+        device = local_rank % max(capi.device_count(), 1)
+        u0 = capi.checkerboard_host(n, n)
+        for b in range(images):
+            gb = rank * images + b
+            planes = image_planes(name, n, gb)
+            p = capi.make_params(tol=0.0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]) if C == 3 else capi.make_params(tol=0.0)
+            ctx = capi.Context(n, n, C, p, device=device)
+            ctx.set_option("math_mode", math_mode)
+            ctx.set_option("finalize", args.finalize)
+            for kv in args.opt:
+                k, v = kv.split("=")
+                ctx.set_option(k, int(v))
+            ctx.set_image(planes)
+            if name == "C4":   # the pre-smoother is its own timed phase (src/main.cpp:940-947 runs it once, before the loop)
+                L_, T_ = 0.25, args.pm_steps * 0.25
+                ctx.perona_malik(30.0, L_, min(T_, 25.0))        # warm-up: <= 100 steps, then the planes are restored
+                ctx.set_image(planes)
+                ctx.perona_malik(30.0, L_, T_)
+                pm_ms = ctx.last_pm_ms()
+                trips = capi.pm_trip_count(L_, T_)
+                pm_bytes = 16.0 * n * n * C                      # read + write the FP64 state of every plane per step
+                pm_info = {"steps": trips, "K": 30.0, "L": L_, "T": T_, "us_per_step": pm_ms * 1e3 / max(trips, 1),
+                           "value": float(n) * n * C * trips / (pm_ms / 1e3) / 1e6, "unit": "Mplane-pixel-steps/s",
+                           "roofline": {"bound": "hbm", "achieved": pm_bytes * trips / (pm_ms / 1e3) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": pm_bytes * trips / (pm_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_launch": pm_bytes, "traffic": None}}
+            ctx.set_levelset(u0)
+            ctxs.append(ctx)
 
     def run_steps(k):
         # interleave the images' streams in chunks so their kernels overlap on the GPU
@@ -105,68 +195,90 @@ def main():
 
     run_steps(args.warmup)
     sync_all()
+    for ctx in ctxs:
+        ctx.warm(min(steps, 8 if len(ctxs) > 1 else 16))   # hipGraph capture/instantiate is one-off host work: not a step
     barrier()
     sync_all()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(steps)
     res = sync_all()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms = [ctx.last_run_ms() for ctx in ctxs]  # HIP events on each image's stream
-    assert all(r[0] == args.warmup + args.steps and not r[2] for r in res), res
+    elapsed = (t1 - t0) if not dry else 1.0 + 0.25 * rank
+    if not dry:
+        kernel_ms = [ctx.last_run_ms() for ctx in ctxs]  # HIP events on each image's stream
+        assert all(r[0] == args.warmup + steps and not r[2] for r in res), res
 
     # end-of-run gather of the per-rank records (the only collective besides barriers/max)
-    records = batch.gather_records(dist, [args.images_per_gpu, float(n) * n * args.steps * args.images_per_gpu, elapsed])
+    records = batch.gather_records(dist, [images, float(n) * n * steps * images, elapsed])
     elapsed = batch.max_over_ranks(dist, elapsed)
-    total_images = world * args.images_per_gpu
     value = batch.aggregate_throughput(records, elapsed)
 
     out = None
     if rank == 0:
         bytes_per_launch = (2 * 8 + C) * float(n) * n      # read u, write u, read C planes
-        avg_launch_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3 / args.steps
-        if args.images_per_gpu > 1:
-            avg_launch_s /= args.images_per_gpu            # streams overlap: per-launch share of the span
+        avg_launch_s = max((sum(kernel_ms) / len(kernel_ms)) / 1e3 / max(steps, 1), 1e-12)
+        if images > 1:
+            avg_launch_s /= images                         # streams overlap: per-launch share of the span
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"csv_step_{n}x{n}x{C}")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"csv_step_{n}x{n}x{C}")
+                traffic_source = tj.get("_source") if traffic is not None else None
             except Exception:
                 traffic = None
-        workload = (f"{n}x{n} {C}-channel synthetic disk, checkerboard init, {args.steps} CSV iterations, tol 0"
-                    + (" (BASELINE configs[1])" if (n, C, args.steps, total_images) == (4096, 1, 500, 1) else ""))
         kopt = dict(kv.split("=") for kv in (args.opt or [])).get("kernel", "-1")
         two_px = C == 1 and n % 16 == 0 and n >= 144 and (kopt == "3" or (kopt == "-1" and n * n <= 40000000))   # api.hip resolve_geometry
         kernel_name = {"0": "csv_step_kernel (tile)", "1": "csv_strip_kernel"}.get(kopt, "csv_wave2_kernel" if two_px else "csv_wave_kernel")
+        workload = f"{name}: {n}x{n} {C}-channel {desc}, checkerboard init, {steps} CSV iterations after {args.warmup} warm-up, tol 0"
         out = {
             "metric": "Mpixel-iterations/s (CSV u-update)",
             "value": value,
             "unit": "Mpixel-iterations/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
+            "ms_per_step": elapsed * 1e3 / max(steps, 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": workload, "images_per_gpu": args.images_per_gpu,
+            "data": "synthetic" if not dry else "dry-run",
+            "config": {"workload": workload, "images_per_gpu": images, "images_total": images * world,
                        "state": "fp64", "math": args.math, "parallelism": f"batch-shard x{world}",
+                       "ranks_in_group": (dist.get_world_size() if dist is not None else 1),
+                       "backend": (dist.get_backend() if dist is not None else "none"),
                        "per_rank_mpx_it_s": [r[1] / r[2] / 1e6 for r in records]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, C, args.cpu_iters)
+        if pm_info is not None:
+            out["pm"] = pm_info
+
+    # (N=1) the same run split by phase: iterations 1-16 (every pixel of the checkerboard is in the near
+    # field of H_eps), 17-100, 101-500; one sync per segment, nothing else in the timed spans
+    if world == 1 and not dry and not args.no_phases and images == 1:
+        ctx = ctxs[0]
+        ctx.set_levelset(u0)
+        phases = {}
+        lo = 1
+        for seg in (16, 84, 400):
+            ctx.warm(seg)
+            ctx.enqueue_steps(seg)
+            ctx.sync()
+            phases[f"{lo}-{lo + seg - 1}"] = ctx.last_run_ms() * 1e3 / seg
+            lo += seg
+        out["phases"] = {"unit": "us per iteration (HIP events)", **phases}
 
     for ctx in ctxs:
         ctx.close()
+    if out is not None and world == 1 and not dry and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(name, n, C, args.cpu_iters)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -174,13 +286,20 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(n, C, iters):
-    """The CPU oracle (kind 'port': same pass structure and OpenMP team sizes as the
-    reference, src/main.cpp:963-1001) on `iters` iterations of the same image."""
-    import numpy as np
-    from chan_vese_amd import synth
+def cpu_baseline(name, n, C, iters):
+    """The CPU oracle (kind 'port': same pass structure and OpenMP team sizes as the reference,
+    src/main.cpp:963-1001 and :478-560) on a bounded sample of the same workload."""
     from oracle import cv_oracle as O
-    planes = synth.config_planes("C2" if C == 1 else "C3", n)
+    planes = image_planes(name, n, 0)
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    extra = {}
+    if name == "C4":   # the pre-smoother: a few steps of the same plane (serial per channel, as the reference)
+        pm_steps = 8
+        t0 = time.perf_counter()
+        O.perona_malik(planes, 30.0, 0.25, pm_steps * 0.25)
+        dt = time.perf_counter() - t0
+        extra["pm"] = {"value": float(n) * n * C * pm_steps / dt / 1e6, "unit": "Mplane-pixel-steps/s",
+                       "sample": f"{pm_steps} Perona-Malik steps of the {n}x{n} plane ({dt:.1f} s), serial per channel as the reference"}
     u = O.checkerboard(n, n)
     p = O.make_params(tol=0.0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]) if C == 3 else O.make_params(tol=0.0)
     O.csv_step(planes, u, p)  # warm-up (page faults, thread pool)
@@ -188,12 +307,11 @@ def cpu_baseline(n, C, iters):
     for _ in range(iters):
         O.csv_step(planes, u, p)
     dt = time.perf_counter() - t0
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": float(n) * n * iters / dt / 1e6, "unit": "Mpixel-iterations/s", "cores": threads,
             "kind": "port",
             "sample": f"{iters} CSV iterations of the same {n}x{n}x{C} image after 1 warm-up iteration "
                       f"({dt:.1f} s); OpenMP teams as the reference: 3 threads in curvature(), "
-                      f"{threads} for the delta map, c1/c2 sweeps serial"}
+                      f"{threads} for the delta map, c1/c2 sweeps serial", **extra}
 
 
 if __name__ == "__main__":

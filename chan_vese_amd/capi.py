@@ -21,7 +21,7 @@ EXPORTS = [
     "cvh_default_params", "cvh_device_count", "cvh_create", "cvh_destroy", "cvh_last_error",
     "cvh_set_params", "cvh_set_option", "cvh_set_image", "cvh_get_image", "cvh_set_levelset",
     "cvh_get_levelset", "cvh_init_checkerboard", "cvh_levelset_checkerboard_host", "cvh_run",
-    "cvh_enqueue_steps", "cvh_sync", "cvh_reset_run", "cvh_get_means", "cvh_get_trace",
+    "cvh_enqueue_steps", "cvh_warm", "cvh_sync", "cvh_reset_run", "cvh_get_means", "cvh_get_trace",
     "cvh_get_stop_condition", "cvh_get_mask", "cvh_get_contour", "cvh_separate", "cvh_perona_malik",
     "cvh_pm_trip_count", "cvh_last_run_ms", "cvh_last_pm_ms", "cvh_ppf_apply",
     "cvh_ppf_apply_device", "cvh_version",
@@ -72,6 +72,7 @@ def lib():
         "cvh_levelset_checkerboard_host": (None, [C.c_int, C.c_int, dp]),
         "cvh_run": (C.c_int, [vp, C.c_int, ip, dp]),
         "cvh_enqueue_steps": (C.c_int, [vp, C.c_int]),
+        "cvh_warm": (C.c_int, [vp, C.c_int]),
         "cvh_sync": (C.c_int, [vp, ip, dp, ip]),
         "cvh_reset_run": (C.c_int, [vp]),
         "cvh_get_means": (C.c_int, [vp, dp, dp]),
@@ -220,6 +221,10 @@ class Context:
 
     def enqueue_steps(self, n):
         self._chk(self._L.cvh_enqueue_steps(self._h, int(n)))
+
+    def warm(self, n):
+        """One-off host work of an upcoming enqueue_steps(n) (graph build), outside any timed region."""
+        self._chk(self._L.cvh_warm(self._h, int(n)))
 
     def sync(self):
         """Returns (steps_done_total, last_norm, stopped)."""

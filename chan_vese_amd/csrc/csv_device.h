@@ -232,7 +232,17 @@ __device__ __forceinline__ void publish_partials_and_maybe_finalize(const CvhSte
 {
   constexpr int NS = cvh_nsums(C);
   const int tid = threadIdx.x;
-  // write-through (sc1) stores of this workgroup's row, drained before the ticket
+  // Hand-off of the partial rows to the last-arriving workgroup.  This is the hardware-level form that
+  // /opt/skills/guides/MI355X_MICROARCH.md (Workgroup dispatch ... inter-workgroup visibility, "Valid forms",
+  // first table row) documents as measured-valid on gfx950 in place of a language-level release/acquire pair:
+  //   producer: EVERY handed-off byte stored write-through (`sc1`: relaxed agent-scope atomic store), the storing
+  //             wave drains them (`s_waitcnt vmcnt(0)`), and only then ONE lane of the same wave adds to the counter;
+  //   consumer: the workgroup whose add returned nblocks-1 loads every handed-off byte with `sc1` loads
+  //             (relaxed agent-scope atomic loads in finalize()), after a workgroup barrier that the adding wave joins.
+  // A language-level __ATOMIC_RELEASE on the ticket would lower to `buffer_wbl2 sc1` (a write-back of the XCD's
+  // whole L2, ~1.7-6.5 us per workgroup on this critical path) and buy nothing here: the rows never sit dirty in L2.
+  // The acquire fence below is kept for the plain loads of the state words (c1/c2/steps_done of the previous launch).
+  // gfx950-only by design (this library targets nothing else); not a portable C++ memory-model hand-off.
   if (tid < NS)
     __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NS + tid], total, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);

@@ -9,6 +9,14 @@
 
 #define CVH_BLOCK 256  // 4 waves of 64
 
+// Ablation / diagnostic keys of cvh_set_option (not part of include/chanvese_hip.h; defaults are what ships):
+//   "wave_occupancy" waves per SIMD the wave kernels' grid is sized for (3..5; kernel 2: 5, kernel 3: 3),
+//   "wave_depth" rows per group (4, 8), "wave_prio" s_setprio progress equalisation (0 off, 1 quarters,
+//   2-4 thresholds crowded to the end, 5 clock-paced), "wave_sync" workgroup barrier per group (1),
+//   "wave_imgv" 16-byte image pieces (1), "wave_xcd" XCD-contiguous workgroup numbering (1),
+//   "wave_skew" per-mille strip-length skew (0), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
+//   read with cvh_debug_read, tools/wave_timeline.py).
+
 // Device-resident scalar state of one context.  Written only by the finalising workgroup
 // of a kernel and read by the next kernel on the same stream (kernel boundary = visibility).
 struct CvhState {

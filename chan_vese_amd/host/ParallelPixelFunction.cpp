@@ -66,10 +66,14 @@ ParallelPixelFunction::ParallelPixelFunction(cv::Mat &_data, int _w, ChanVese::P
 
 void ParallelPixelFunction::operator()(const cv::Range &r) const
 {
-  if (op_ == ChanVese::PixelOp::Unknown)
-    throw std::invalid_argument("ParallelPixelFunction: the callable is none of regularized_delta, "
-                                "regularized_heaviside, 1 - regularized_heaviside; an opaque std::function "
-                                "cannot run on the GPU and this build has no CPU fallback");
+  if (op_ == ChanVese::PixelOp::Unknown) {
+    // Any other callable keeps the reference's semantics exactly (src/ParallelPixelFunction.cpp:12-17):
+    // the caller's own function, applied on the host over [start, end).  (An opaque std::function
+    // cannot run on a GPU; this loop is the caller's code, not a CPU copy of the library's kernels.)
+    for (int i = r.start; i < r.end; ++i)
+      data.at<double>(i / w, i % w) = func(data.at<double>(i / w, i % w));
+    return;
+  }
   if (data.type() != CV_64FC1 || !data.isContinuous())
     throw std::invalid_argument("ParallelPixelFunction: data must be a continuous CV_64FC1 matrix");
   // data.at<double>(i / w, i % w) for i in [start, end)  (src/ParallelPixelFunction.cpp:15-16)

@@ -6,11 +6,12 @@
 // `virtual void operator()(const cv::Range&) const`, usable with cv::parallel_for_ exactly
 // as at src/main.cpp:988-989.  An opaque std::function cannot execute on a GPU, so:
 //   * the tagged constructor (data, w, PixelOp, eps) names the function directly;
-//   * the std::function constructor IDENTIFIES the callable by probing it at a few points
-//     against the three functions the reference ever maps over pixels — regularized_delta
-//     (src/main.cpp:204-210), regularized_heaviside (:188-194) and the Outside lambda
-//     1 - heaviside (:267) — and recovers their epsilon.  A callable that is none of them
-//     makes operator() throw std::invalid_argument: there is NO CPU fallback.
+//   * the std::function constructor IDENTIFIES the callable by probing it (about 20 calls at fixed
+//     arguments -- observable for a stateful functor) against the three functions the reference ever
+//     maps over pixels -- regularized_delta (src/main.cpp:204-210), regularized_heaviside (:188-194)
+//     and the Outside lambda 1 - heaviside (:267) -- and recovers their epsilon; a positive match runs
+//     on the GPU.  Any OTHER callable keeps the reference's behaviour (src/ParallelPixelFunction.cpp:12-17):
+//     operator() applies the caller's function on the host, data(i/w, i%w) = func(data(i/w, i%w)).
 // operator()(Range(a,b)) replaces elements [a,b) of the flat index range of the w-wide
 // CV_64FC1 matrix by f(x), in place (src/ParallelPixelFunction.cpp:15-16), on the GPU.
 #ifndef PARALLELPIXELFUNCTION_HPP

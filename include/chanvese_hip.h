@@ -101,17 +101,11 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
  *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
  *   "dma"            tile kernel: 1 = global->LDS DMA loader (slower on MI355X, default 0)
- *   wave kernel:  "wave_occupancy" waves per SIMD the grid is sized for (3..5, default 5; kernel 3: 4),
- *                 "wave_depth" rows per group (4 default, 8), "wave_prio" s_setprio progress
- *                 equalisation (0 off, 1 quarters (default), 2-4 thresholds crowded to the end),
- *                 "wave_sync" workgroup barrier per group (default 1), "wave_imgv" 16-byte image
- *                 pieces (default 1), "wave_xcd" XCD-contiguous workgroup numbering (default 1),
- *                 "wave_skew" per-mille strip-length skew (default 0), "wave_lds_cap",
- *                 "wave_rev", "debug_times" (diagnostics)
  *   "pm_kernel"      Perona-Malik data flow: -1 auto (2 from 12 Mpixel planes on, else 1), 0 LDS tile,
  *                    1 wave-streaming, 2 wave-streaming with 2 pixels per lane (even w >= 128)
  *   "pm_strip_rows"  Perona-Malik wave kernel: rows per strip (0 auto)
- * Unknown keys and out-of-range values return CVH_ERR_ARG. */
+ * (Ablation / diagnostic knobs of the wave kernels are not part of this interface: they are listed in
+ * chan_vese_amd/csrc/cvh_internal.h.)  Unknown keys and out-of-range values return CVH_ERR_ARG. */
 int cvh_set_option(cvh_context *ctx, const char *key, long value);
 
 /* Uploads the C channel planes (what cv::split produced, src/main.cpp:934-937). */
@@ -143,6 +137,11 @@ int cvh_run(cvh_context *ctx, int max_steps, int *steps_done, double *last_norm)
  * independent images) on one GPU: enqueue `nsteps` iterations on the context's stream,
  * later wait for them.  `stopped` reports whether the stop rule fired. */
 int cvh_enqueue_steps(cvh_context *ctx, int nsteps);
+/* Optional: does the one-off host work of an upcoming cvh_enqueue_steps(ctx, nsteps) now (strip table,
+ * capture + instantiation of the 16-step hipGraph of the current ping-pong parity), so that a caller
+ * timing the enqueue/sync pair with its own clock does not see it.  cvh_run and cvh_enqueue_steps do the
+ * same work themselves before they open cvh_last_run_ms's interval. */
+int cvh_warm(cvh_context *ctx, int nsteps);
 int cvh_sync(cvh_context *ctx, int *steps_done_total, double *last_norm, int *stopped);
 /* Clears the iteration counter and the stop flag (cvh_run does this itself). */
 int cvh_reset_run(cvh_context *ctx);

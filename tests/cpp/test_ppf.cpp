@@ -34,7 +34,8 @@ int main()
     else if (op == 1) cv::parallel_for_(cv::Range(0, h * w), ParallelPixelFunction(u_cp, w, heaviside));
     else if (op == 2) cv::parallel_for_(cv::Range(0, h * w), ParallelPixelFunction(u_cp, w, [&heaviside](double x) -> double { return 1 - heaviside(x); }));
     else if (op == 3) cv::parallel_for_(cv::Range(3, h * w - 2), ParallelPixelFunction(u_cp, w, ChanVese::PixelOp::Delta, eps));
-    else cv::parallel_for_(cv::Range(0, h * w), ParallelPixelFunction(u_cp, w, [](double x) { return std::sin(x); }));
+    else if (op == 9) cv::parallel_for_(cv::Range(0, h * w), ParallelPixelFunction(u_cp, w, [](double x) { return std::sin(x); }));
+    else cv::parallel_for_(cv::Range(2, h * w - 5), ParallelPixelFunction(u_cp, w, [](double x) { return x * x; }));
   } catch (const std::exception &e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 3;

@@ -65,3 +65,24 @@ def test_two_rank_gloo_gather_and_max(tmp_path):
     assert d["recs"] == [[32.0, 32000.0, 1.0], [32.0, 32000.0, 1.5]]
     assert d["emax"] == 1.5
     assert d["value"] == pytest.approx(64000.0 / 1.5 / 1e6)
+
+
+def test_bench_gpus_flag_spawns_ranks_dry_run():
+    """`python bench.py --gpus 2` started directly (no launcher) must start 2 ranks itself and report
+    n_gpus == 2.  CHANVESE_BENCH_DRYRUN=1 skips the GPU work, so this covers the launch / barrier / gather /
+    report path on CPU with gloo; the line is marked "dry-run" and carries no measurement."""
+    import json
+    env = dict(os.environ, CHANVESE_DIST_BACKEND="gloo", CHANVESE_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_group"] == 2 and d["data"] == "dry-run"
+    assert d["config"]["images_per_gpu"] == 8 and d["config"]["images_total"] == 16   # C5 share per GPU
+    assert len(d["config"]["per_rank_mpx_it_s"]) == 2
+    # whole-job value = all pixel-iterations / slowest rank's time (rank 1 reports 1.25 s in the dry run)
+    assert d["value"] == pytest.approx(2 * 8 * 3 * 4096.0 * 4096.0 / 1.25 / 1e6)

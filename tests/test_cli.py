@@ -128,7 +128,8 @@ def test_cli_colour_lambda_order_is_bgr(cli, oracle, tmp_path):
 @pytest.mark.gpu
 def test_cpp_parallel_pixel_function_operator(cli, oracle):
     """tests/cpp/test_ppf.cpp: the reference's call site (src/main.cpp:988-989) compiled against
-    include/ParallelPixelFunction.hpp; std::function callables are recognised and run on the GPU."""
+    include/ParallelPixelFunction.hpp; the three known std::function callables are recognised and run on the GPU, any other one
+    runs on the host as in the reference."""
     exe = os.path.join(ROOT, "bin", "test_ppf")
     rng = np.random.default_rng(5)
     h, w, eps = 9, 13, 0.75
@@ -144,9 +145,16 @@ def test_cpp_parallel_pixel_function_operator(cli, oracle):
         else:
             oracle.ppf_apply(want, op, eps)
         assert np.allclose(got, want, rtol=1e-15, atol=3e-16)
-    inp = f"{h} {w} {eps} 9\n" + "\n".join(repr(float(v)) for v in x.ravel()) + "\n"
-    r = subprocess.run([exe], input=inp, capture_output=True, text=True, timeout=120)
-    assert r.returncode == 3 and "no CPU fallback" in r.stderr       # an unknown callable is refused loudly
+    # any other callable: the reference's own semantics (src/ParallelPixelFunction.cpp:12-17), the caller's
+    # function applied on the host over [start, end)
+    for op, fn, lo, hi in ((9, np.sin, 0, h * w), (10, np.square, 2, h * w - 5)):
+        inp = f"{h} {w} {eps} {op}\n" + "\n".join(repr(float(v)) for v in x.ravel()) + "\n"
+        r = subprocess.run([exe], input=inp, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        got = np.array([float(t) for t in r.stdout.split()])
+        want = x.ravel().copy()
+        want[lo:hi] = fn(want[lo:hi])
+        assert np.allclose(got, want, rtol=4e-16, atol=0)
 
 
 def _passthrough(cli, path, *extra):

@@ -1,0 +1,214 @@
+"""GPU parity at the PRODUCTION launch geometry and over long runs (run with -m gpu on an MI355X).
+
+The small-shape tests (test_gpu_parity.py) cannot reach what bench.py launches: 765 workgroups, 90 strips x 33
+wave-columns, XCD renumbering with a grid that is not a multiple of 8, hipGraph chunks of 16 steps.  Here the
+default kernel / geometry / graph path runs the BASELINE.json configurations at full size against the CPU oracle
+(the oracle costs ~0.8 s per iteration at 4096^2, so the oracle-checked runs are 5-16 iterations), plus long runs
+checked at the end-of-run tolerance and through size-independent properties.
+
+Tolerances: max|u_gpu - u_cpu| / max|u_cpu| <= 1e-9 over the first iterations, <= 1e-6 after the
+configured count; c1/c2/norm relative <= 1e-9 per iteration; mask equal (IoU >= 0.999 after long runs)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from chan_vese_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from chan_vese_amd import capi as m
+    m.lib()
+    assert m.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return m
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def iou(a, b):
+    a, b = a.astype(bool), b.astype(bool)
+    u = (a | b).sum()
+    return 1.0 if u == 0 else (a & b).sum() / u
+
+
+def gpu_steps(capi, planes, u0, steps, pk, opts=None, via_enqueue=False):
+    """Default kernel, default geometry, default (graph) launch path."""
+    h, w = planes[0].shape
+    with capi.Context(h, w, len(planes), capi.make_params(**pk)) as ctx:
+        for k, v in (opts or {}).items():
+            ctx.set_option(k, v)
+        ctx.set_option("trace", steps)
+        ctx.set_image(planes)
+        ctx.set_levelset(u0)
+        if via_enqueue:          # what bench.py does: chunks of 16 = one hipGraph each
+            done = 0
+            while done < steps:
+                c = min(16, steps - done)
+                ctx.enqueue_steps(c)
+                done += c
+            done, nrm, _ = ctx.sync()
+        else:
+            done, nrm = ctx.run(steps)
+        return ctx.get_levelset(), done, nrm, ctx.get_trace(steps), ctx.get_mask()
+
+
+def test_config2_4096_one_channel_bench_geometry(capi, oracle):
+    """BASELINE configs[1] at full size: 4096x4096x1 disk, checkerboard init, the launch bench.py times
+    (csv_wave2_kernel, 765 workgroups, hipGraph of 16 steps + 2 plain launches) vs the oracle, 18 iterations."""
+    n, steps = 4096, 18
+    img = synth.config_planes("C2", n)
+    u0 = oracle.checkerboard(n, n)
+    pk = dict(tol=0)
+    u_c, done_c, nrm_c, tr_c = oracle.csv_run(img, u0, oracle.make_params(**pk), steps)
+    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, img, u0, steps, pk, via_enqueue=True)
+    assert done_g == done_c == steps
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+    assert nrm_g == pytest.approx(nrm_c, rel=1e-9)
+    assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+def test_config5_image_4096_noisy(capi, oracle):
+    """One image of BASELINE configs[4] (noise 16, seed 1003, radius 1020) at full size, 6 iterations via cvh_run."""
+    n, steps = 4096, 6
+    img = [synth.batch_image(3, n)]
+    u0 = oracle.checkerboard(n, n)
+    pk = dict(tol=0)
+    u_c, _, nrm_c, tr_c = oracle.csv_run(img, u0, oracle.make_params(**pk), steps)
+    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, img, u0, steps, pk)
+    assert done_g == steps
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+    assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+def test_config3_4096_three_channel(capi, oracle):
+    """BASELINE configs[2] at full size: 4096x4096x3, per-channel lambda, 5 iterations."""
+    n, steps = 4096, 5
+    planes = synth.config_planes("C3", n)
+    u0 = oracle.checkerboard(n, n)
+    pk = dict(tol=0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1])
+    u_c, _, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
+    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, planes, u0, steps, pk)
+    assert done_g == steps
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+    assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+def test_config4_2048_pm_then_csv(capi, oracle):
+    """BASELINE configs[3] at full size, shortened: the 2048x2048 noisy disk, Perona-Malik K=30 L=0.25 T=5 (20 steps,
+    uint8 result compared exactly up to the round-half-even boundary), then 10 CSV iterations on the smoothed plane."""
+    n = 2048
+    img = synth.config_planes("C4", n)
+    pm_c = oracle.perona_malik(img, 30.0, 0.25, 5.0)
+    u0 = oracle.checkerboard(n, n)
+    pk = dict(tol=0)
+    with capi.Context(n, n, 1, capi.make_params(**pk)) as ctx:
+        ctx.set_image(img)
+        ctx.perona_malik(30.0, 0.25, 5.0)
+        pm_g = ctx.get_image()
+        diff = pm_g[0].astype(int) - pm_c[0].astype(int)
+        assert np.abs(diff).max() <= 1 and (diff != 0).mean() <= 1e-6      # FAST: <= 1 LSB on <= 1e-6 of the pixels
+        ctx.set_image(pm_c)       # identical input for the CSV part even if a boundary pixel rounded the other way
+        ctx.set_option("trace", 10)
+        ctx.set_levelset(u0)
+        done, nrm = ctx.run(10)
+        u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(10), ctx.get_mask()
+    u_c, _, nrm_c, tr_c = oracle.csv_run(pm_c, u0, oracle.make_params(**pk), 10)
+    assert done == 10
+    assert rel_err(u_g, u_c) <= 1e-9
+    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+    assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+def test_512_disk_500_iterations_drift(capi, oracle):
+    """Long-run drift (SURVEY §8d "re-measure at 500"): 512x512 disk, 500 iterations, end-of-run tolerance 1e-6,
+    IoU >= 0.999 (expected 1.0), c1/c2/norm of every iteration within 1e-6 relative (the recurrence amplifies the
+    1e-16-level differences of the first iterations)."""
+    n, steps = 512, 500
+    img = synth.config_planes("C1", n)
+    u0 = oracle.checkerboard(n, n)
+    pk = dict(tol=0)
+    u_c, done_c, nrm_c, tr_c = oracle.csv_run(img, u0, oracle.make_params(**pk), steps)
+    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, img, u0, steps, pk)
+    assert done_g == done_c == steps
+    assert rel_err(u_g, u_c) <= 1e-6, rel_err(u_g, u_c)
+    assert np.allclose(tr_g[:10], tr_c[:10], rtol=1e-9, atol=0)
+    assert np.allclose(tr_g, tr_c, rtol=1e-6, atol=0)
+    assert iou(m_g, oracle.mask(u_c)) >= 0.999
+    assert iou(m_g, synth.disk(n) > 100) == 1.0
+
+
+def test_4096_500_iterations_properties(capi, oracle, golden_dir):
+    """BASELINE configs[1] for its full 500 iterations (no oracle at this length: ~7 minutes of CPU): bitwise
+    repeatable (fixed-order reductions, no float atomics), the mask IS the disk, c1/c2 settle at the disk's
+    foreground / background as the 512^2 oracle trajectory (tests/golden/traj_512_disk.npz) does."""
+    n, steps = 4096, 500
+    img = synth.config_planes("C2", n)
+    u0 = oracle.checkerboard(n, n)
+    pk = dict(tol=0)
+    u_a, done_a, nrm_a, tr_a, m_a = gpu_steps(capi, img, u0, steps, pk, via_enqueue=True)
+    u_b, done_b, nrm_b, tr_b, m_b = gpu_steps(capi, img, u0, steps, pk)      # cvh_run: other chunking, same arithmetic
+    assert done_a == done_b == steps
+    assert np.array_equal(u_a, u_b) and np.array_equal(tr_a, tr_b) and nrm_a == nrm_b
+    assert iou(m_a, img[0] > 100) == 1.0
+    assert np.all(np.isfinite(u_a))
+    c1, c2 = tr_a[-1, 0], tr_a[-1, 1]
+    assert abs(c1 - 200) < 2.5 and abs(c2 - 50) < 0.5          # region means of the segmented disk
+    tr512 = np.load(os.path.join(golden_dir, "traj_512_disk.npz"))["trace"]   # oracle trajectory of the same disk family at 512^2
+    # iteration 100: c1/c2 agree up to the discretisation of the disk edge (a thinner share of the pixels at 4096^2)
+    assert abs(tr512[-1, 0] - tr_a[99, 0]) < 2.0 and abs(tr512[-1, 1] - tr_a[99, 1]) < 0.5
+
+
+@pytest.mark.parametrize("shape", [(1, 144), (144, 1), (3, 700), (100, 517), (150, 530), (9, 272), (64, 2016)])
+@pytest.mark.parametrize("mode,math", [("strict", 1), ("fast", 2)])
+def test_csv_three_channel_edge_shapes(capi, oracle, shape, mode, math):
+    """3 channels on the shapes the 1-channel kernels are tested on: one row, one column, ragged widths (w % 16 != 0),
+    ragged strips, a width that is an exact multiple of the wave stride."""
+    h, w = shape
+    rng = np.random.default_rng(h * 31337 + w)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]
+    u0 = oracle.checkerboard(h, w) if min(h, w) > 2 else rng.normal(size=shape)
+    pk = dict(tol=0, lambda1=[1, 0.8, 0.5], lambda2=[0.7, 0.5, 1], nu=0.01)
+    for steps, opts in ((1, {}), (7, dict(strip_rows=8)), (4, dict(kernel=2))):
+        u_c, _, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
+        with capi.Context(h, w, 3, capi.make_params(**pk)) as ctx:
+            ctx.set_option("math_mode", math)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.set_option("trace", steps)
+            ctx.set_image(planes)
+            ctx.set_levelset(u0)
+            done, nrm = ctx.run(steps)
+            u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(steps), ctx.get_mask()
+        assert done == steps
+        assert rel_err(u_g, u_c) <= 1e-9, (steps, opts, rel_err(u_g, u_c))
+        assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+        assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+def test_bench_gpus_2_gloo_on_one_gpu():
+    """`python bench.py --gpus 2` started directly spawns two ranks (both on device 0 under
+    CHANVESE_DIST_BACKEND=gloo), runs the batch-shard workload on the GPU and prints one line with n_gpus == 2."""
+    env = dict(os.environ, CHANVESE_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "CHANVESE_BENCH_DRYRUN"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "512", "--steps", "40",
+                          "--warmup", "8", "--images-per-gpu", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_group"] == 2 and d["data"] == "synthetic"
+    assert d["config"]["images_total"] == 4 and len(d["config"]["per_rank_mpx_it_s"]) == 2
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
