@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--no-phases", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--pm-steps", type=int, default=1000, help="C4: Perona-Malik steps (T = steps * 0.25)")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="device clock warm-up before the W warm-up steps: this many ms of the same kernel on a SCRATCH "
+                         "context (own buffers; the measured level sets are not touched). 0 = off")
     return ap.parse_args(argv)
 
 
@@ -193,6 +196,24 @@ def main():
     def barrier():
         batch.barrier(dist)
 
+    # Device warm-up, not part of W or K: a cold process runs its first ~100 launches 8-10 % slower (DVFS ramp from the
+    # idle clock; profiles/README.md), whatever they compute.  The same kernel runs on a scratch context with its own
+    # buffers, so the level sets being measured still see exactly W warm-up + K timed iterations.
+    prewarm_launches = 0
+    if ctxs and args.prewarm_ms > 0:
+        scratch = capi.Context(n, n, C, capi.make_params(tol=0.0), device=device)
+        scratch.set_option("math_mode", math_mode)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            scratch.set_option(k, int(v))
+        scratch.set_image(image_planes(name, n, rank * images))
+        scratch.set_levelset(u0)
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+            scratch.enqueue_steps(64)
+            scratch.sync()
+            prewarm_launches += 64
+        scratch.close()
     run_steps(args.warmup)
     sync_all()
     for ctx in ctxs:
@@ -248,7 +269,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not dry else "dry-run",
             "config": {"workload": workload, "images_per_gpu": images, "images_total": images * world,
-                       "state": "fp64", "math": args.math, "parallelism": f"batch-shard x{world}",
+                       "state": "fp64", "math": args.math,
+                       "device_prewarm": f"{prewarm_launches} launches on a scratch context before the warm-up steps", "parallelism": f"batch-shard x{world}",
                        "ranks_in_group": (dist.get_world_size() if dist is not None else 1),
                        "backend": (dist.get_backend() if dist is not None else "none"),
                        "per_rank_mpx_it_s": [r[1] / r[2] / 1e6 for r in records]},

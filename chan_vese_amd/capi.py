@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libchanvese_hip.so")
+# CHANVESE_HIP_LIB selects another BUILD of the same library (A/B variants under csrc/variants/, tools/build_variant.sh)
+LIB_PATH = os.environ.get("CHANVESE_HIP_LIB") or os.path.join(_HERE, "csrc", "libchanvese_hip.so")
 
 CVH_OK = 0
 OP_DELTA, OP_HEAVISIDE, OP_ONE_MINUS_HEAVISIDE = 0, 1, 2

@@ -12,7 +12,7 @@
 #include "cvh_internal.h"
 
 constexpr int kGraphSteps = 16;   // steps per captured graph (even: the ping-pong parity repeats)
-struct StepGraph { hipGraphExec_t exec = nullptr; CvhStepArgs key[2]; int kind = -1, flavour = -1; };
+struct StepGraph { hipGraphExec_t exec = nullptr; CvhStepArgs key[4]; int kind = -1, flavour = -1; };
 
 struct cvh_context {
   int h = 0, w = 0, C = 0, device = 0;
@@ -43,6 +43,15 @@ struct cvh_context {
   int use_graph = 1;
   StepGraph graphs[2];          // by ping-pong parity of the first step
   int wave_skew = 0;            // per-mille: older workgroups get longer strips (see upload_strip_bounds)
+  // chain mode of the 2-pixel wave kernel (cvh_internal.h, CvhChainAcc)
+  CvhChainAcc *d_chain = nullptr;
+  int chain_opt = 1;            // option "chain"
+  int chain_pb = 0;             // sum set that belongs to the level set at run-counter 0
+  bool chain_pending = false;   // chain launches enqueued since the last flush
+  bool chain_acc_valid = false; // the fixed-point sets hold the sums of the current level set
+  int far_terms = 5;            // terms of the far-field series of H_eps (5: valid from 32 eps, 4: from 64 eps)
+  int wave_cls = 1;             // 2-pixel wave kernel: class-major workgroup numbering (dispatch rounds)
+  int wave_cskew = 0;           // per-mille strip-length skew between dispatch rounds (see upload_strip_bounds)
   int *d_bounds = nullptr;      // wave kernel: first row of every strip, [tiles_y + 1]
   int bounds_key[4] = {-1, -1, -1, -1};
   int *h_status = nullptr;  // pinned + mapped: {steps_done, stopped} written by the device
@@ -137,6 +146,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (int k = 0; k < 2; ++k) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
+  if (c->d_chain) (void)hipFree(c->d_chain);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->h_status) (void)hipHostFree(c->h_status);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -186,6 +196,8 @@ static int create_impl(cvh_context *c)
   HIPCHK(c, hipMalloc((void **)&c->d_partials, (size_t)c->partial_rows * cvh_nsums(c->C) * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_dummy, (size_t)(c->w > 64 ? c->w : 64) * sizeof(double)));
   HIPCHK(c, hipMalloc((void **)&c->d_bounds, (size_t)(c->h + 2) * sizeof(int)));
+  HIPCHK(c, hipMalloc((void **)&c->d_chain, sizeof(CvhChainAcc)));
+  HIPCHK(c, hipMemset(c->d_chain, 0, sizeof(CvhChainAcc)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_status, 64, hipHostMallocMapped));
   c->h_status[0] = 0; c->h_status[1] = 0;
   HIPCHK(c, hipEventCreate(&c->ev0));
@@ -234,10 +246,13 @@ extern "C" int cvh_set_params(cvh_context *c, const cvh_params *p)
   return CVH_OK;
 }
 
+static int sync_impl(cvh_context *c);
+
 extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
 {
   if (!c || !key) return CVH_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }  // options apply between runs
   if (!strcmp(key, "math_mode")) {
     if (value < 0 || value > 2) return fail(c, CVH_ERR_ARG, "math_mode must be 0, 1 or 2");
     c->math_mode = (int)value;
@@ -277,6 +292,16 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "wave_skew")) {
     if (value < 0 || value > 500) return fail(c, CVH_ERR_ARG, "wave_skew must be 0..500 (per mille)");
     c->wave_skew = (int)value;
+  } else if (!strcmp(key, "chain")) {
+    c->chain_opt = value != 0;
+  } else if (!strcmp(key, "far_terms")) {
+    if (value != 4 && value != 5) return fail(c, CVH_ERR_ARG, "far_terms must be 4 or 5");
+    c->far_terms = (int)value;
+  } else if (!strcmp(key, "wave_cls")) {
+    c->wave_cls = value != 0;
+  } else if (!strcmp(key, "wave_cskew")) {
+    if (value < 0 || value > 300) return fail(c, CVH_ERR_ARG, "wave_cskew must be 0..300 (per mille)");
+    c->wave_cskew = (int)value;
   } else if (!strcmp(key, "wave_depth")) {
     if (value != 4 && value != 8) return fail(c, CVH_ERR_ARG, "wave_depth must be 4 or 8");
     c->wave_depth = (int)value;
@@ -375,12 +400,16 @@ static int current_buffer(const cvh_context *c) { return (c->cur_base + c->steps
 
 static int reset_run_impl(cvh_context *c)
 {
-  // new run: counter and stop flag cleared; the buffer holding u becomes the base
+  if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
+  // new run: counter and stop flag cleared; the buffer holding u becomes the base, and so does the chain-mode sum set
+  // that belongs to it (the set after it may hold the sums of an iteration computed past a stop: cleared)
   c->cur_base = current_buffer(c);
+  c->chain_pb = (c->chain_pb + c->steps_done) & 3;
   c->steps_done = 0;
   c->enqueued = 0;
-  const int zeros[2] = {0, 0};
+  static const int zeros[4] = {0, 0, 0, 0};   // steps_done, stopped, ticket, pending
   HIPCHK(c, hipMemcpyAsync(&c->d_state->steps_done, zeros, sizeof(zeros), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(&c->d_chain->v[(c->chain_pb + 1) & 3][0][0], 0, sizeof(c->d_chain->v[0]), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->h_status[0] = 0; c->h_status[1] = 0;
   return CVH_OK;
@@ -397,6 +426,7 @@ extern "C" int cvh_set_levelset(cvh_context *c, const double *u)
 {
   if (!c || !u) return CVH_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cur_base = 0; c->steps_done = 0; c->enqueued = 0;
   HIPCHK(c, hipMemcpyAsync(c->d_u[0], u, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -521,7 +551,13 @@ static Geometry resolve_geometry(const cvh_context *c)
   return g;
 }
 
-static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
+static bool use_chain(const cvh_context *c, const Geometry &g)
+{
+  return g.strip == 3 && use_fast(c) && c->finalize_mode == 0 && c->chain_opt;
+}
+
+// `step` = index of the launch inside the run (c->enqueued when it is enqueued): selects the chain-mode sum set
+static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step)
 {
   memset(a, 0, sizeof(*a));
   a->u_in = c->d_u[in_buf];
@@ -557,6 +593,21 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
   a->strip_bounds = c->d_bounds;
   a->wave_rev = c->wave_rev;
   a->wave_xcd = c->wave_xcd;
+  if (use_chain(c, g)) {
+    a->chain = c->d_chain;
+    a->chain_pb = c->chain_pb;
+    a->chain_phase = (c->chain_pb + step) & 3;
+    a->chain_s4 = c->d_partials;   // [2][nparts] rows of sum u_diff^2 (the workspace holds far more)
+    // |sum (H - 1/2)| <= N/2 and |sum I (H - 1/2)| <= 255 N / 2 for every subset of pixels: 62 - ceil(log2(bound + 1)) fraction bits
+    const double bound[2] = {0.5 * (double)c->n, 127.5 * (double)c->n};
+    for (int k = 0; k < 2; ++k) {
+      int e = 0;
+      while (ldexp(1.0, e) < bound[k] + 1.0) ++e;
+      a->chain_scale[k] = ldexp(1.0, 62 - e);
+      a->chain_inv[k] = ldexp(1.0, e - 62);
+    }
+  }
+  a->wave_cls = (g.strip == 3 && c->wave_cls && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
   a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
   a->inv_eps = 1.0 / c->p.eps;
@@ -566,7 +617,11 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf)
     const double e = c->p.eps, e2 = e * e;
     a->far_k[0] = e / pi; a->far_k[1] = -(e * e2) / (3.0 * pi);
     a->far_k[2] = (e * e2 * e2) / (5.0 * pi); a->far_k[3] = -(e * e2 * e2 * e2) / (7.0 * pi);
-    a->far_thr = 64.0 * e;
+    // 5 terms (through t^9/9, t = eps/|u|): next term t^11/11 <= 2.5e-18 for |u| >= 32 eps.  With 4 terms the threshold
+    // is 64 eps ("far_terms" = 4: far_k[4] = 0) -- the 4096^2 checkerboard run then spends iterations 3..13 in the near field
+    // (|u| grows from 36 to 64 there), with 5 terms only iterations 1..2.
+    a->far_k[4] = c->far_terms == 5 ? (e * e2 * e2 * e2 * e2) / (9.0 * pi) : 0.0;
+    a->far_thr = (c->far_terms == 5 ? 32.0 : 64.0) * e;
   }
   a->stop_cond = c->stop_cond_h;
   a->npix = (double)c->n;
@@ -603,14 +658,17 @@ static int prepare(cvh_context *c)
   int rc0 = prepare_host(c);
   if (rc0 != CVH_OK) return rc0;
   HIPCHK(c, hipMemcpyAsync(&c->d_state->stop_cond, &c->stop_cond_h, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const bool chain = use_chain(c, resolve_geometry(c));
+  if (chain && !c->chain_acc_valid) c->sums_valid = false;   // the means exist only as doubles (another kernel ran): recompute
   if (!c->sums_valid) {
     CvhStepArgs a;
-    fill_args(c, &a, current_buffer(c));
+    fill_args(c, &a, current_buffer(c), c->enqueued);
     int nparts = 0;
     HIPCHK(c, cvh_launch_init_sums(a, c->C, use_fast(c), &nparts, c->stream));
     a.nparts = nparts;
-    HIPCHK(c, cvh_launch_finalize(a, c->C, 1, c->stream));
+    HIPCHK(c, cvh_launch_finalize(a, c->C, 1, c->stream));   // chain mode: also seeds the fixed-point set of this step
     c->sums_valid = true;
+    c->chain_acc_valid = chain;
   }
   return CVH_OK;
 }
@@ -622,16 +680,50 @@ static int prepare(cvh_context *c)
 // (1 + alpha) to (1 - alpha) times the mean with the strip index, so they finish together.
 static int upload_strip_bounds(cvh_context *c, const Geometry &g)
 {
-  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew, c->h};
+  const int cls = (g.strip == 3 && c->wave_cls && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
+  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0), c->h};
   if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
   const int S = g.tiles_y;
   std::vector<int> b((size_t)S + 1);
-  const double alpha = c->wave_skew / 1000.0;
-  for (int k = 0; k <= S; ++k) {
-    long v;
-    if (c->wave_skew == 0) v = (long)k * g.strip_rows;
-    else { const double x = (double)k / S; v = (long)((double)c->h * (x + alpha * x * (1.0 - x))); }
-    b[k] = (int)(v < c->h ? v : c->h);
+  if (cls) {
+    // 2-pixel kernel, class-major numbering (csv_wave2_kernel.hip): the hardware deals workgroup b to XCD b % 8 and,
+    // inside an XCD, the first `cls` workgroups to distinct CUs, the next `cls` to the same CUs again, ... (measured,
+    // tools/wave_timeline.py: a CU holds workgroups j, j + 32, j + 64 of its XCD, in wave slots 0, 1, 2).  At equal
+    // priority the SIMD arbiter serves the OLDEST wave first, so round 0 finishes 4 us before round 1 and 8 us before
+    // round 2 (53 / 57 / 61 us) and the tail of every launch runs at 2, then 1 wave per SIMD.  The class-major numbering
+    // makes the strips of one round contiguous, and wave_cskew = 1000 a gives the rounds (1 + a), 1, (1 - a) times the
+    // mean strip length so that all rounds finish together.  Rows are dealt by cumulative weight: no short last strip.
+    const int nbc = (g.tiles_x + 1) / 2, nb = g.nblocks, q = nb >> 3, r = nb & 7;
+    const int npairs = (S + 1) / 2;
+    int ncls = 0;
+    std::vector<long> K;                       // K[k] = workgroups in rounds 0..k
+    for (;; ++ncls) {
+      long tot = 0;
+      for (int x = 0; x < 8; ++x) { const int nx = q + (x < r ? 1 : 0); const long lim = (long)(ncls + 1) * cls; tot += nx < lim ? nx : lim; }
+      K.push_back(tot);
+      if (tot >= nb) { ++ncls; break; }
+    }
+    const double a_ = c->wave_cskew / 1000.0, mid = (ncls - 1) / 2.0;
+    std::vector<double> wgt((size_t)S);
+    double total = 0;
+    for (int sp = 0; sp < npairs; ++sp) {
+      const long rank = (long)sp * nbc + nbc / 2;
+      int k = 0;
+      while (k < ncls - 1 && rank >= K[k]) ++k;
+      const double wv = 1.0 + a_ * (mid - k) / (mid > 0 ? mid : 1.0);
+      for (int t = 0; t < 2 && 2 * sp + t < S; ++t) { wgt[2 * sp + t] = wv; total += wv; }
+    }
+    double cum = 0;
+    for (int k = 0; k < S; ++k) { b[k] = (int)((double)c->h * (cum / total) + 0.5); cum += wgt[k]; }
+    for (int k = 1; k < S; ++k) if (b[k] < b[k - 1]) b[k] = b[k - 1];
+  } else {
+    const double alpha = c->wave_skew / 1000.0;
+    for (int k = 0; k <= S; ++k) {
+      long v;
+      if (c->wave_skew == 0) v = (long)k * g.strip_rows;
+      else { const double x = (double)k / S; v = (long)((double)c->h * (x + alpha * x * (1.0 - x))); }
+      b[k] = (int)(v < c->h ? v : c->h);
+    }
   }
   b[S] = c->h;
   HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
@@ -640,16 +732,31 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
   return CVH_OK;
 }
 
-static int launch_one_step(cvh_context *c, int in_buf)
+static int launch_one_step(cvh_context *c, int in_buf, int step)
 {
   CvhStepArgs a;
-  fill_args(c, &a, in_buf);
+  fill_args(c, &a, in_buf, step);
   const int kind = resolve_geometry(c).strip;
   if (kind == 3) HIPCHK(c, cvh_launch_wave2(a, use_fast(c), c->stream));
   else if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
   else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
   else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
   if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
+  if (a.chain) c->chain_pending = true;
+  else c->chain_acc_valid = false;   // the means now live in the state block only
+  return CVH_OK;
+}
+
+// Chain mode: the last launch's iteration has no successor to book it -- one small kernel does (norm, stop rule,
+// trace row) and writes the region means of the current level set into the state block.
+static int chain_flush(cvh_context *c)
+{
+  if (!c->chain_pending) return CVH_OK;
+  CvhStepArgs a;
+  fill_args(c, &a, 0, 0);
+  if (!a.chain) return fail(c, CVH_ERR_STATE, "chain-mode launches are pending but the context no longer selects chain mode");
+  HIPCHK(c, cvh_launch_chain_flush(a, c->stream));
+  c->chain_pending = false;
   return CVH_OK;
 }
 
@@ -660,15 +767,15 @@ static int launch_one_step(cvh_context *c, int in_buf)
 static int ensure_step_graph(cvh_context *c, int parity)
 {
   StepGraph &g = c->graphs[parity];
-  CvhStepArgs key[2];
-  fill_args(c, &key[0], parity);
-  fill_args(c, &key[1], parity ^ 1);
+  // the arguments of consecutive steps differ in the ping-pong parity and the chain-mode sum set: period 4
+  CvhStepArgs key[4];
+  for (int s = 0; s < 4; ++s) fill_args(c, &key[s], parity ^ (s & 1), c->enqueued + s);
   const int kind = resolve_geometry(c).strip, flavour = (use_fast(c) ? 1 : 0) | (c->finalize_mode << 1);
   if (g.exec && g.kind == kind && g.flavour == flavour && !memcmp(key, g.key, sizeof(key))) return CVH_OK;
   if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = CVH_OK;
-  for (int s = 0; s < kGraphSteps && rc == CVH_OK; ++s) rc = launch_one_step(c, parity ^ (s & 1));
+  for (int s = 0; s < kGraphSteps && rc == CVH_OK; ++s) rc = launch_one_step(c, parity ^ (s & 1), c->enqueued + s);
   hipGraph_t graph = nullptr;
   const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
   if (rc != CVH_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -709,11 +816,12 @@ static int enqueue_impl(cvh_context *c, int nsteps)
     const int rc = ensure_step_graph(c, parity);
     if (rc != CVH_OK) return rc;
     HIPCHK(c, hipGraphLaunch(c->graphs[parity].exec, c->stream));
+    if (c->graphs[parity].key[0].chain) c->chain_pending = true; else c->chain_acc_valid = false;
     c->enqueued += kGraphSteps;
     s += kGraphSteps;
   }
   for (; s < nsteps; ++s) {
-    const int rc = launch_one_step(c, (c->cur_base + c->enqueued) & 1);
+    const int rc = launch_one_step(c, (c->cur_base + c->enqueued) & 1, c->enqueued);
     if (rc != CVH_OK) return rc;
     c->enqueued++;
   }
@@ -753,10 +861,10 @@ static int absorb_state(cvh_context *c, const CvhState *hs)
   return CVH_OK;
 }
 
-extern "C" int cvh_sync(cvh_context *c, int *steps_done_total, double *last_norm, int *stopped)
+static int sync_impl(cvh_context *c)
 {
-  if (!c) return CVH_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  int rc = chain_flush(c);
+  if (rc != CVH_OK) return rc;
   if (c->timing_open) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -765,6 +873,16 @@ extern "C" int cvh_sync(cvh_context *c, int *steps_done_total, double *last_norm
     c->timing_open = false;
   }
   absorb_state(c, &c->h_state[0]);
+  if (!c->h_state[0].stopped) c->enqueued = c->steps_done;
+  return CVH_OK;
+}
+
+extern "C" int cvh_sync(cvh_context *c, int *steps_done_total, double *last_norm, int *stopped)
+{
+  if (!c) return CVH_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = sync_impl(c);
+  if (rc != CVH_OK) return rc;
   if (steps_done_total) *steps_done_total = c->h_state[0].steps_done;
   if (last_norm) *last_norm = c->h_state[0].norm;
   if (stopped) *stopped = c->h_state[0].stopped;
@@ -777,8 +895,7 @@ extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *l
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->have_image) return fail(c, CVH_ERR_STATE, "no image set (call cvh_set_image first)");
   if (!c->have_u) return fail(c, CVH_ERR_STATE, "no level set (call cvh_set_levelset or cvh_init_checkerboard first)");
-  if (c->timing_open) { int rc0 = cvh_sync(c, nullptr, nullptr, nullptr); if (rc0 != CVH_OK) return rc0; }
-  int rc = reset_run_impl(c);
+  int rc = reset_run_impl(c);   // settles whatever is in flight first
   if (rc != CVH_OK) return rc;
   long remaining = max_steps < 0 ? (long)INT_MAX : (long)max_steps;  // src/main.cpp:890
   rc = prepare_host(c);  // one-off host work (src/main.cpp:950-959) stays outside the device timing
@@ -807,12 +924,9 @@ extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *l
     remaining -= chunk;
     queued += chunk;
   }
-  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipEventElapsedTime(&c->last_run_ms, c->ev0, c->ev1));
-  c->timing_open = false;
-  absorb_state(c, &c->h_state[0]);
+  c->timing_open = true;   // sync_impl closes the interval opened at ev0 (after the chain-mode flush)
+  rc = sync_impl(c);
+  if (rc != CVH_OK) return rc;
   c->enqueued = c->steps_done;
   if (steps_done) *steps_done = c->h_state[0].steps_done;
   if (last_norm) *last_norm = c->h_state[0].norm;

@@ -187,6 +187,17 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
   if (a.dbg_times && tid == 0 && !is_init) a.dbg_times[(size_t)a.nparts * 18 + 3] = __builtin_amdgcn_s_memrealtime();
   if (tid < NS) sfin[tid] = total;
   __syncthreads();
+  if (is_init && a.chain) {
+    // chain mode (csv_wave2_kernel.hip): seed the fixed-point sum set this step reads with the sums of the initial level
+    // set (centred: minus N/2 and sum(I)/2), all in shard 0, and clear the set the first launch adds into
+    const double centred[2] = {sfin[0] - 0.5 * a.npix, sfin[2] - 0.5 * a.sum_img[0]};
+    for (int i = tid; i < 4 * CVH_CHAIN_SHARDS; i += CVH_BLOCK) {
+      const int second = i >= 2 * CVH_CHAIN_SHARDS, j = i & (2 * CVH_CHAIN_SHARDS - 1), sum = j / CVH_CHAIN_SHARDS, shard = j % CVH_CHAIN_SHARDS;
+      long long v = 0;
+      if (!second && shard == 0) v = __double2ll_rn(centred[sum] * a.chain_scale[sum]);
+      a.chain->v[(a.chain_phase + second) & 3][sum][shard] = v;
+    }
+  }
   if (tid == 0) {
     CvhState *st = a.st;
     if (a.derive_complement && !is_init) {
@@ -221,6 +232,7 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
       st->c2[k] = sfin[2 + C + k] / sfin[1];
     }
     st->ticket = 0;
+    if (is_init) st->pending = 0;
   }
 }
 

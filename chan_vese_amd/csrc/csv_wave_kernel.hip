@@ -78,7 +78,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   for (int k = 0; k < C; ++k) { c1[k] = a.st->c1[k]; c2[k] = a.st->c2[k]; l1[k] = a.lambda1[k]; l2[k] = a.lambda2[k]; }
   const double eps = a.eps;
   const double eps2 = eps * eps;
-  const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_thr};
+  const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_k[4], a.far_thr};
 
   // the tables are filled while the first rows are in flight: see fill_tables() below
   auto fill_tables = [&]() {

@@ -14,7 +14,8 @@
 //   "wave_depth" rows per group (4, 8), "wave_prio" s_setprio progress equalisation (0 off, 1 quarters,
 //   2-4 thresholds crowded to the end, 5 clock-paced), "wave_sync" workgroup barrier per group (1),
 //   "wave_imgv" 16-byte image pieces (1), "wave_xcd" XCD-contiguous workgroup numbering (1),
-//   "wave_skew" per-mille strip-length skew (0), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
+//   "wave_skew" per-mille strip-length skew (0), "wave_cls" class-major numbering of the 2-pixel kernel (1),
+//   "wave_cskew" per-mille strip-length skew between dispatch rounds (kernel 3), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
 //   read with cvh_debug_read, tools/wave_timeline.py).
 
 // Device-resident scalar state of one context.  Written only by the finalising workgroup
@@ -27,8 +28,16 @@ struct CvhState {
   int steps_done;               // iterations executed since cvh_reset_run
   int stopped;                  // sticky: stop rule fired (:1000); later launches are no-ops
   unsigned ticket;              // arrival counter of the in-kernel finalisation
-  int pad;
+  int pending;                  // chain mode: the iteration of the last launch still awaits its bookkeeping (norm, stop test)
 };
+
+// Chain mode of the 2-pixel wave kernel (csv_wave2_kernel.hip): the two sums the NEXT iteration needs, sum (H - 1/2)
+// and sum I (H - 1/2), are accumulated as 64-bit FIXED-POINT integers with agent-scope atomic adds -- integer addition
+// is associative, so the result is bitwise reproducible whatever the arrival order -- into one of four rotating sets
+// of 32 shards (same-address atomics serialise at ~10 ns each; 765 workgroups over 32 shards do not queue).  Launch e
+// reads set (e mod 4), adds into set (e+1 mod 4) and clears set (e+2 mod 4); nothing waits for a last workgroup.
+constexpr int CVH_CHAIN_SETS = 4, CVH_CHAIN_SHARDS = 32;
+struct CvhChainAcc { long long v[CVH_CHAIN_SETS][2][CVH_CHAIN_SHARDS]; };
 
 // Sums carried per workgroup and reduced in a fixed order (deterministic):
 //   [0] sum H(u)  [1] sum (1-H(u))  [2..2+C) sum I_k H  [2+C..2+2C) sum I_k (1-H)  [2+2C] sum u_diff^2
@@ -56,7 +65,7 @@ struct CvhStepArgs {
   double npix;                   // h*w
   double sum_img[CVH_MAX_CHANNELS];  // exact integer sums of the planes (complements are derived)
   double stop_cond;              // tol * ||mean_k I_k||_2 (:959), the value also held in CvhState
-  double far_k[4], far_thr;      // wave kernel, FAST: far-field series of atan(eps/u)/pi and its threshold 64 eps
+  double far_k[5], far_thr;      // wave kernels, FAST: far-field series of atan(eps/u)/pi (5 terms) and its threshold (32 eps)
   int derive_complement;         // sums [1] and [2+C..] are N - sum H, sum I - sum I H; 2: sums [0], [2..] are of H - 1/2
   int tile_rows;                 // rows per tile of the step kernel
   int use_lut;
@@ -75,6 +84,13 @@ struct CvhStepArgs {
   int wave_sync;                 // wave kernel: workgroup barrier every 4 rows
   int wave_prio;                 // progress-based s_setprio in the wave kernel
   int wave_lds_cap;              // pad the LDS request so that at most wave_minw workgroups fit a CU
+  CvhChainAcc *chain;            // chain mode (2-pixel wave kernel, FAST): fixed-point sum sets, or null
+  int chain_phase;               // set this launch reads
+  int chain_pb;                  // set that held the sums of u when the run counter was last reset (flush: set = pb + steps_done)
+  double chain_scale[2], chain_inv[2];   // powers of two: fixed-point scale of sum (H-1/2) / sum I (H-1/2) and their inverses
+  double *chain_s4;              // [2][nparts] per-workgroup sum u_diff^2 rows, by launch parity
+  int wave_cls;                  // 2-pixel wave kernel: workgroups per XCD per dispatch round (= CUs per XCD); > 0 numbers the
+                                 // workgroups class-major (round 0 of every XCD first), 0 = plain XCD-contiguous numbering
 };
 
 #define CVH_ATAN_N 129
@@ -100,6 +116,7 @@ hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStre
 hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave2_cols();
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s);
+hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, hipStream_t s);
 hipError_t cvh_launch_wave(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave_cols();
 hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,

@@ -61,48 +61,76 @@ def gpu_steps(capi, planes, u0, steps, pk, opts=None, via_enqueue=False):
         return ctx.get_levelset(), done, nrm, ctx.get_trace(steps), ctx.get_mask()
 
 
+def check_against_oracle(capi, oracle, planes, pk, steps, restart_at, via_enqueue=False, opts=None):
+    """Three checks of one configuration against the oracle's trajectory u_1 .. u_steps:
+    (a) ONE GPU iteration from the initial level set: <= 1e-12 (nothing to amplify yet);
+    (b) restarts: the oracle's own u_k uploaded, ONE GPU iteration, compared with the oracle's u_{k+1}: <= 1e-9 and
+        c1/c2/norm relative <= 1e-9 -- the sharp test of the launch geometry, free of the recurrence's amplification;
+    (c) the free run of `steps` iterations: <= 1e-6 (SURVEY.md §8d end-of-run tolerance), mask IoU >= 0.999.
+    Why (c) cannot be 1e-9 at 4096^2: after iteration 1 of a checkerboard start c1 and c2 agree to 2.7e-5 relative
+    (79.4504 vs 79.4526), the region term is proportional to c1 - c2, and the REFERENCE's sequential 16.7M-term sums
+    carry ~1e-12 relative rounding error: 3e-8 of max|u| at iteration 2 (measured; it then decays).  The GPU's tree sums
+    are the more accurate of the two."""
+    h, w = planes[0].shape
+    u0 = oracle.checkerboard(h, w)
+    p = oracle.make_params(**pk)
+    u = u0.copy()
+    keep, tr_c = {}, []
+    for t in range(1, steps + 1):
+        if (t - 1) in restart_at:
+            keep[t - 1] = u.copy()
+        nrm, c1, c2 = oracle.csv_step(planes, u, p)      # c1/c2 = the means this iteration used
+        tr_c.append(list(c1) + list(c2) + [nrm])
+        if t == 1 or (t - 1) in restart_at:
+            keep[("after", t - 1)] = u.copy()
+    tr_c = np.array(tr_c)
+    with capi.Context(h, w, len(planes), capi.make_params(**pk)) as ctx:
+        for k, v in (opts or {}).items():
+            ctx.set_option(k, v)
+        ctx.set_option("trace", steps)
+        ctx.set_image(planes)
+        # (a) + (b)
+        for k in [0] + sorted(restart_at):
+            ctx.set_levelset(u0 if k == 0 else keep[k])
+            done, nrm = ctx.run(1)
+            assert done == 1
+            err = rel_err(ctx.get_levelset(), keep[("after", k)])
+            assert err <= (1e-12 if k == 0 else 1e-9), (k, err)
+            tr = ctx.get_trace(1)[0]
+            assert np.allclose(tr, tr_c[k], rtol=1e-9, atol=0), (k, tr, tr_c[k])
+        # (c)
+        ctx.set_levelset(u0)
+        if via_enqueue:          # what bench.py does: chunks of 16 = one hipGraph each
+            done = 0
+            while done < steps:
+                c = min(16, steps - done)
+                ctx.enqueue_steps(c)
+                done += c
+            done, nrm, _ = ctx.sync()
+        else:
+            done, nrm = ctx.run(steps)
+        assert done == steps
+        u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(steps), ctx.get_mask()
+    assert rel_err(u_g, u) <= 1e-6, rel_err(u_g, u)
+    assert np.allclose(tr_g[0], tr_c[0], rtol=1e-9, atol=0)
+    assert np.allclose(tr_g, tr_c, rtol=1e-5, atol=0), np.abs(tr_g / tr_c - 1).max()
+    assert iou(m_g, oracle.mask(u)) >= 0.999
+
+
 def test_config2_4096_one_channel_bench_geometry(capi, oracle):
     """BASELINE configs[1] at full size: 4096x4096x1 disk, checkerboard init, the launch bench.py times
-    (csv_wave2_kernel, 765 workgroups, hipGraph of 16 steps + 2 plain launches) vs the oracle, 18 iterations."""
-    n, steps = 4096, 18
-    img = synth.config_planes("C2", n)
-    u0 = oracle.checkerboard(n, n)
-    pk = dict(tol=0)
-    u_c, done_c, nrm_c, tr_c = oracle.csv_run(img, u0, oracle.make_params(**pk), steps)
-    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, img, u0, steps, pk, via_enqueue=True)
-    assert done_g == done_c == steps
-    assert rel_err(u_g, u_c) <= 1e-9
-    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
-    assert nrm_g == pytest.approx(nrm_c, rel=1e-9)
-    assert np.array_equal(m_g, oracle.mask(u_c))
+    (default kernel and geometry: 765 workgroups, hipGraph of 16 steps + 2 plain launches), 18 iterations."""
+    check_against_oracle(capi, oracle, synth.config_planes("C2", 4096), dict(tol=0), 18, {3, 17}, via_enqueue=True)
 
 
 def test_config5_image_4096_noisy(capi, oracle):
     """One image of BASELINE configs[4] (noise 16, seed 1003, radius 1020) at full size, 6 iterations via cvh_run."""
-    n, steps = 4096, 6
-    img = [synth.batch_image(3, n)]
-    u0 = oracle.checkerboard(n, n)
-    pk = dict(tol=0)
-    u_c, _, nrm_c, tr_c = oracle.csv_run(img, u0, oracle.make_params(**pk), steps)
-    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, img, u0, steps, pk)
-    assert done_g == steps
-    assert rel_err(u_g, u_c) <= 1e-9
-    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
-    assert np.array_equal(m_g, oracle.mask(u_c))
+    check_against_oracle(capi, oracle, [synth.batch_image(3, 4096)], dict(tol=0), 6, {2, 5})
 
 
 def test_config3_4096_three_channel(capi, oracle):
     """BASELINE configs[2] at full size: 4096x4096x3, per-channel lambda, 5 iterations."""
-    n, steps = 4096, 5
-    planes = synth.config_planes("C3", n)
-    u0 = oracle.checkerboard(n, n)
-    pk = dict(tol=0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1])
-    u_c, _, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
-    u_g, done_g, nrm_g, tr_g, m_g = gpu_steps(capi, planes, u0, steps, pk)
-    assert done_g == steps
-    assert rel_err(u_g, u_c) <= 1e-9
-    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
-    assert np.array_equal(m_g, oracle.mask(u_c))
+    check_against_oracle(capi, oracle, synth.config_planes("C3", 4096), dict(tol=0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]), 5, {2, 4})
 
 
 def test_config4_2048_pm_then_csv(capi, oracle):
@@ -126,9 +154,10 @@ def test_config4_2048_pm_then_csv(capi, oracle):
         u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(10), ctx.get_mask()
     u_c, _, nrm_c, tr_c = oracle.csv_run(pm_c, u0, oracle.make_params(**pk), 10)
     assert done == 10
-    assert rel_err(u_g, u_c) <= 1e-9
-    assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
-    assert np.array_equal(m_g, oracle.mask(u_c))
+    assert rel_err(u_g, u_c) <= 1e-6          # free run: see check_against_oracle (c)
+    assert np.allclose(tr_g[0], tr_c[0], rtol=1e-9, atol=0)
+    assert np.allclose(tr_g, tr_c, rtol=1e-5, atol=0)
+    assert iou(m_g, oracle.mask(u_c)) >= 0.999
 
 
 def test_512_disk_500_iterations_drift(capi, oracle):

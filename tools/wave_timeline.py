@@ -65,4 +65,7 @@ for c_ in sorted(set(percu)): print("CUs with", c_, "waves:", (percu == c_).sum(
 mx = np.zeros(len(u_)); mn = np.full(len(u_), 1e9)
 np.maximum.at(mx, inv, en); np.minimum.at(mn, inv, en)
 print("within-CU end spread: median %.1f max %.1f; CU last-end: min %.1f median %.1f max %.1f" % (np.median(mx - mn), (mx - mn).max(), mx.min(), np.median(mx), mx.max()))
+out = __import__("os").environ.get("SAVE")
+if out:   # raw stamps for offline analysis: per wave {start, end, HW_ID, XCC_ID}, block ends, ticket / stored stamps
+    np.savez_compressed(out, w=w, blk_end=blk_end, tick=tick, lastw=lastw, stored=stored, nb=nb, n=n)
 ctx.close()
