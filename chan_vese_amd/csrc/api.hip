@@ -21,6 +21,8 @@ struct cvh_context {
   hipStream_t stream = nullptr;
   uint8_t *d_img[CVH_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
   double *d_u[2] = {nullptr, nullptr};
+  void *d_u_slab = nullptr;
+  size_t u_skew = 0;            // bytes (multiple of 256) between the two level-set buffers beyond a 2 MiB multiple
   CvhState *d_state = nullptr;
   CvhState *h_state = nullptr;  // pinned, four slots for pipelined polling
   double *d_partials = nullptr;
@@ -42,6 +44,9 @@ struct cvh_context {
   int wave_rev = 0, wave_xcd = 1;
   int use_graph = 1;
   StepGraph graphs[2];          // by ping-pong parity of the first step
+  hipGraphExec_t pm_graph = nullptr;   // 16 Perona-Malik steps starting from d_pm[0]
+  CvhPmArgs pm_graph_key{};
+  int pm_graph_kind = -1;
   int wave_skew = 0;            // per-mille: older workgroups get longer strips (see upload_strip_bounds)
   // chain mode of the 2-pixel wave kernel (cvh_internal.h, CvhChainAcc)
   CvhChainAcc *d_chain = nullptr;
@@ -136,7 +141,8 @@ extern "C" void cvh_destroy(cvh_context *c)
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int k = 0; k < CVH_MAX_CHANNELS; ++k) if (c->d_img[k]) (void)hipFree(c->d_img[k]);
-  for (int k = 0; k < 2; ++k) { if (c->d_u[k]) (void)hipFree(c->d_u[k]); if (c->d_pm[k]) (void)hipFree(c->d_pm[k]); }
+  if (c->d_u_slab) (void)hipFree(c->d_u_slab);
+  for (int k = 0; k < 2; ++k) if (c->d_pm[k]) (void)hipFree(c->d_pm[k]);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->d_partials) (void)hipFree(c->d_partials);
@@ -145,6 +151,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_atan) (void)hipFree(c->d_atan);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (int k = 0; k < 2; ++k) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
+  if (c->pm_graph) (void)hipGraphExecDestroy(c->pm_graph);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
   if (c->d_chain) (void)hipFree(c->d_chain);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
@@ -167,7 +174,18 @@ static int create_impl(cvh_context *c)
   for (int k = 0; k < c->C; ++k) HIPCHK(c, hipMalloc((void **)&c->d_img[k], c->n));
   // 64 doubles of slack behind each level-set buffer: the wave kernel parks the stores of lanes
   // that own no pixel there (see csv_wave_kernel.hip)
-  for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc((void **)&c->d_u[k], (c->n + 64) * sizeof(double)));
+  {
+    // one slab for the ping-pong pair; the second buffer starts `u_skew` bytes past a 2 MiB boundary so that row r of the
+    // buffer being read and row r of the buffer being written do not map to the same memory channels at the same time
+    // (hipMalloc blocks are 2 MiB aligned: two separate allocations are congruent modulo every interleave period)
+    const size_t each = (((c->n + 64) * sizeof(double)) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    size_t skew = c->u_skew;
+    if (const char *e = getenv("CVH_U_SKEW")) skew = (size_t)strtoul(e, nullptr, 0);
+    skew &= ~(size_t)255;
+    HIPCHK(c, hipMalloc((void **)&c->d_u_slab, 2 * each + skew + 256));
+    c->d_u[0] = (double *)c->d_u_slab;
+    c->d_u[1] = (double *)((char *)c->d_u_slab + each + skew);
+  }
   HIPCHK(c, hipMalloc((void **)&c->d_state, sizeof(CvhState)));
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_state, 4 * sizeof(CvhState), hipHostMallocDefault));
@@ -1076,16 +1094,45 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   } else {
     cvh_pm_grid(c->h, c->w, &a.tiles_x, &a.tiles_y);
   }
+  const int kind = pm_wave2 ? 2 : (pm_wave ? 1 : 0);
+  auto launch_pm = [&](const CvhPmArgs &pa) -> hipError_t {
+    return kind == 2 ? cvh_launch_pm_wave2(pa, c->stream) : (kind == 1 ? cvh_launch_pm_wave(pa, c->stream) : cvh_launch_pm_step(pa, c->stream));
+  };
+  // kGraphSteps steps as one hipGraph, as for the CSV step: a graph node costs 1.6 us against 2.8 us for a stream launch
+  // (tools/launch_probe.hip) and a 2048^2 step is only ~13 us.  The graph always starts from d_pm[0] (16 is even).
+  if (c->use_graph && trips >= kGraphSteps) {
+    CvhPmArgs key = a;
+    key.in = c->d_pm[0]; key.out = c->d_pm[1];
+    if (!c->pm_graph || c->pm_graph_kind != kind || memcmp(&key, &c->pm_graph_key, sizeof(key))) {
+      if (c->pm_graph) { (void)hipGraphExecDestroy(c->pm_graph); c->pm_graph = nullptr; }
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      hipError_t e = hipSuccess;
+      for (int t = 0; t < kGraphSteps && e == hipSuccess; ++t) {
+        CvhPmArgs pa = a;
+        pa.in = c->d_pm[t & 1]; pa.out = c->d_pm[(t & 1) ^ 1];
+        e = launch_pm(pa);
+      }
+      hipGraph_t graph = nullptr;
+      const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+      if (e != hipSuccess || e_end != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(c, CVH_ERR_HIP, "cvh_perona_malik: graph capture failed (%s)", hipGetErrorString(e != hipSuccess ? e : e_end));
+      }
+      const hipError_t e_inst = hipGraphInstantiate(&c->pm_graph, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e_inst != hipSuccess) { c->pm_graph = nullptr; return fail(c, CVH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e_inst)); }
+      c->pm_graph_key = key; c->pm_graph_kind = kind;
+    }
+  }
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   if (trips > 0) {
     for (int k = 0; k < c->C; ++k) {
       HIPCHK(c, cvh_launch_pm_load(c->d_img[k], c->d_pm[0], c->n, c->stream));
-      int cur = 0;
-      for (int t = 0; t < trips; ++t) {
+      int cur = 0, t = 0;
+      for (; c->use_graph && c->pm_graph && trips - t >= kGraphSteps; t += kGraphSteps) HIPCHK(c, hipGraphLaunch(c->pm_graph, c->stream));
+      for (; t < trips; ++t) {
         a.in = c->d_pm[cur]; a.out = c->d_pm[cur ^ 1];
-        if (pm_wave2) HIPCHK(c, cvh_launch_pm_wave2(a, c->stream));
-        else if (pm_wave) HIPCHK(c, cvh_launch_pm_wave(a, c->stream));
-        else HIPCHK(c, cvh_launch_pm_step(a, c->stream));
+        HIPCHK(c, launch_pm(a));
         cur ^= 1;
       }
       HIPCHK(c, cvh_launch_pm_store(c->d_pm[cur], c->d_img[k], c->n, c->stream));

@@ -440,6 +440,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       }
       park(T, X, IQ);
     };
+    const unsigned long long t_first = a.dbg_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // prologue done
+    if (a.dbg_times && lane == 0) a.dbg_times[(size_t)(blockIdx.x * 4 + wave) * 4 + 2] = t_first;
     int ib = s0;
     for (; ib + 2 * R <= ulast; ib += R) group(ib, std::true_type{});
     for (; ib < s1; ib += R) group(ib, std::false_type{});
@@ -460,8 +462,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    d[2] = hwid;
-    d[3] = xcc;
+    d[3] = (unsigned long long)xcc | ((unsigned long long)hwid << 8);   // d[2] = time the first group started
   }
   const double total = block_reduce<NS>(acc, sred);
   if (chain) {

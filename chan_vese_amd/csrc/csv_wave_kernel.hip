@@ -446,8 +446,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    d[2] = hwid;
-    d[3] = xcc;
+    d[2] = d[0];   // (the 2-pixel kernel stamps its first group here)
+    d[3] = (unsigned long long)xcc | ((unsigned long long)hwid << 8);
   }
   const double total = block_reduce<NS>(acc, sred);
   publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, s_last, gridDim.x);

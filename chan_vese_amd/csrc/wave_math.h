@@ -85,7 +85,16 @@ __device__ __forceinline__ double heaviside_centred_near(double u, double inv_ep
 __device__ __forceinline__ double normalised4(double fwd, double bwd, double centre2)
 {
   const double a = __builtin_fma(fwd, 2.0, -centre2), d = fwd - bwd;
+#ifdef CVH_RSQ_NEWTON
+  // A/B build: hardware estimate + ONE Newton step folded into the product (one FP64 operation less per call, ~2^-46)
+  const double s = __builtin_fma(a, a, __builtin_fma(d, d, 4.0 * kEta2));
+  const double r = __builtin_amdgcn_rsq(s);
+  const double e = __builtin_fma(-(s * r), r, 1.0);
+  const double ar = a * r;
+  return __builtin_fma(ar * e, 0.5, ar);
+#else
   return a * rsqrt_refined(__builtin_fma(a, a, __builtin_fma(d, d, 4.0 * kEta2)));
+#endif
 }
 
 __device__ __forceinline__ double dpp_from_left(double v)

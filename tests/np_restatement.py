@@ -85,3 +85,33 @@ def perona_malik(img, K, L, trips):
     for _ in range(trips):
         I = pm_step(I, K, L)
     return np.clip(np.rint(I), 0, 255).astype(np.uint8), I
+
+
+def video_contour(u):
+    """VideoWriterManager::draw_contour (src/VideoWriterManager.cpp:60-74) written independently of
+    oracle/cv_oracle.c: mask = uint8(round-half-even(u)) > 0, cvFindContours clears the image's outer
+    ring first, every border pixel (a set pixel with a cleared 4-neighbour) of every component is drawn 1 px wide."""
+    r = np.rint(np.nan_to_num(u, nan=0.0))
+    m = (np.clip(r, 0, 255).astype(np.uint8) > 0)
+    m[0, :] = False; m[-1, :] = False; m[:, 0] = False; m[:, -1] = False
+    p = np.pad(m, 1, mode="constant", constant_values=False)
+    all4 = p[:-2, 1:-1] & p[2:, 1:-1] & p[1:-1, :-2] & p[1:-1, 2:]
+    return (m & ~all4).astype(np.uint8)
+
+
+def levelset_rect(h, w, x, y, rw, rh):
+    """InteractiveDataRect::get_levelset (src/InteractiveDataRect.cpp:20-27): zeros with ones on the rectangle
+    cv::Rect(x, y, rw, rh) clipped to the image."""
+    u = np.zeros((h, w))
+    u[max(y, 0):max(min(y + rh, h), 0), max(x, 0):max(min(x + rw, w), 0)] = 1.0
+    return u
+
+
+def combine_unfused(kappa, u_diff, mu, nu, dt, C):
+    """src/main.cpp:985 evaluated operation by operation (NOT what the oracle does: OpenCV's MatExpr folds
+    a*K - s + U/c and the outer dt*(...) into ONE addWeighted(K, dt*mu, U, dt/C, -dt*nu))."""
+    return dt * ((mu * kappa - nu) + u_diff * (1.0 / C))
+
+
+def combine_folded(kappa, u_diff, mu, nu, dt, C):
+    return kappa * (mu * dt) + u_diff * ((1.0 / C) * dt) + (-nu * dt)

@@ -36,7 +36,9 @@ d2 = (tick.astype(np.int64) - stored.astype(np.int64)) / 100.0
 print("finalize: partial rows loaded %.2f, reduced %.2f" % ((lastw[2] - t0) / 100.0, (lastw[3] - t0) / 100.0))
 print("per block: waves end -> stored: p50 %.2f max %.2f ; stored -> ticket: p50 %.2f max %.2f" % (np.median(d1), d1.max(), np.median(d2), d2.max()))
 xcc = w[ok, 3] & 0xf
-hw = w[ok, 2]
+hw = w[ok, 3] >> 8
+first = (w[ok, 2].astype(np.int64) - np.int64(t0)) / 100.0
+print('first group starts us: min %.2f p50 %.2f p90 %.2f max %.2f (kernel 3 only)' % (first.min(), np.median(first), np.percentile(first, 90), first.max()))
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 key = xcc * 1000 + se * 100 + sh * 16 + cu
 u, cnt = np.unique(key, return_counts=True)
