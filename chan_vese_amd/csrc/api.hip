@@ -56,7 +56,8 @@ struct cvh_context {
   bool chain_acc_valid = false; // the fixed-point sets hold the sums of the current level set
   int far_terms = 5;            // terms of the far-field series of H_eps (5: valid from 32 eps, 4: from 64 eps)
   int wave_cls = 1;             // 2-pixel wave kernel: class-major workgroup numbering (dispatch rounds)
-  int wave_cskew = 0;           // per-mille strip-length skew between dispatch rounds (see upload_strip_bounds)
+  int wave_cskew = 500;         // per-mille strip-length skew between dispatch rounds (see upload_strip_bounds); measured
+                                // in one process at 4096^2: 0 -> 61.1, 300 -> 59.3, 500 -> 58.7, 750 -> 58.5, 900 -> 59.2 us
   int *d_bounds = nullptr;      // wave kernel: first row of every strip, [tiles_y + 1]
   int bounds_key[4] = {-1, -1, -1, -1};
   int *h_status = nullptr;  // pinned + mapped: {steps_done, stopped} written by the device
@@ -285,7 +286,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
   } else if (!strcmp(key, "pm_kernel")) {
-    if (value < -1 || value > 2) return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave) or 2 (wave, 2 pixels per lane)");
+    if (value < -1 || value > 3) return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave), 2 (wave, 2 pixels per lane) or 3 (wave, 2 time steps per launch)");
     c->pm_kernel = (int)value;
   } else if (!strcmp(key, "pm_strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
@@ -318,7 +319,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "wave_cls")) {
     c->wave_cls = value != 0;
   } else if (!strcmp(key, "wave_cskew")) {
-    if (value < 0 || value > 300) return fail(c, CVH_ERR_ARG, "wave_cskew must be 0..300 (per mille)");
+    if (value < 0 || value > 900) return fail(c, CVH_ERR_ARG, "wave_cskew must be 0..900 (per mille)");
     c->wave_cskew = (int)value;
   } else if (!strcmp(key, "wave_depth")) {
     if (value != 4 && value != 8) return fail(c, CVH_ERR_ARG, "wave_depth must be 4 or 8");
@@ -427,7 +428,7 @@ static int reset_run_impl(cvh_context *c)
   c->enqueued = 0;
   static const int zeros[4] = {0, 0, 0, 0};   // steps_done, stopped, ticket, pending
   HIPCHK(c, hipMemcpyAsync(&c->d_state->steps_done, zeros, sizeof(zeros), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(&c->d_chain->v[(c->chain_pb + 1) & 3][0][0], 0, sizeof(c->d_chain->v[0]), c->stream));
+  HIPCHK(c, hipMemsetAsync(&c->d_chain->v[(c->chain_pb + 1) & 3][0], 0, sizeof(c->d_chain->v[0]), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->h_status[0] = 0; c->h_status[1] = 0;
   return CVH_OK;
@@ -513,7 +514,9 @@ static Geometry resolve_geometry(const cvh_context *c)
     if (sr <= 0) {
       const int occ = use_fast(c) ? (c->wave_minw == 4 ? 4 : 3) : 2;   // as compiled: cvh_launch_wave2
       int nstrips = 2 * ((c->num_cus * occ) / nbc);
-      if (nstrips > 160) nstrips = 128;
+      // small planes (a full round would mean strips of < 13 rows: 3 halo rows and a pipeline fill each): ~1.8 workgroups
+      // per CU instead -- measured at 2048^2: 16 rows 23.2, 18 rows 24.1, 20 rows 21.4, 22 rows 22.7, 24 rows 22.8 us
+      if (nstrips > 160) { nstrips = 2 * (int)(c->num_cus * 1.8 / nbc + 0.5); if (nstrips < 2) nstrips = 2; }
       if (nstrips < 1) nstrips = 1;
       sr = (c->h + nstrips - 1) / nstrips;
       if (sr < 8) sr = 8;
@@ -571,7 +574,7 @@ static Geometry resolve_geometry(const cvh_context *c)
 
 static bool use_chain(const cvh_context *c, const Geometry &g)
 {
-  return g.strip == 3 && use_fast(c) && c->finalize_mode == 0 && c->chain_opt;
+  return (g.strip == 3 || g.strip == 2) && use_fast(c) && c->finalize_mode == 0 && c->chain_opt;
 }
 
 // `step` = index of the launch inside the run (c->enqueued when it is enqueued): selects the chain-mode sum set
@@ -617,15 +620,15 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
     a->chain_phase = (c->chain_pb + step) & 3;
     a->chain_s4 = c->d_partials;   // [2][nparts] rows of sum u_diff^2 (the workspace holds far more)
     // |sum (H - 1/2)| <= N/2 and |sum I (H - 1/2)| <= 255 N / 2 for every subset of pixels: 62 - ceil(log2(bound + 1)) fraction bits
-    const double bound[2] = {0.5 * (double)c->n, 127.5 * (double)c->n};
-    for (int k = 0; k < 2; ++k) {
+    const double bound[4] = {0.5 * (double)c->n, 127.5 * (double)c->n, 127.5 * (double)c->n, 127.5 * (double)c->n};
+    for (int k = 0; k < 4; ++k) {
       int e = 0;
       while (ldexp(1.0, e) < bound[k] + 1.0) ++e;
       a->chain_scale[k] = ldexp(1.0, 62 - e);
       a->chain_inv[k] = ldexp(1.0, e - 62);
     }
   }
-  a->wave_cls = (g.strip == 3 && c->wave_cls && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
+  a->wave_cls = ((g.strip == 3 || g.strip == 2) && c->wave_cls && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
   a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
   a->inv_eps = 1.0 / c->p.eps;
@@ -698,8 +701,8 @@ static int prepare(cvh_context *c)
 // (1 + alpha) to (1 - alpha) times the mean with the strip index, so they finish together.
 static int upload_strip_bounds(cvh_context *c, const Geometry &g)
 {
-  const int cls = (g.strip == 3 && c->wave_cls && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
-  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0), c->h};
+  const int cls = ((g.strip == 3 || g.strip == 2) && c->wave_cls && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
+  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip, c->h};
   if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
   const int S = g.tiles_y;
   std::vector<int> b((size_t)S + 1);
@@ -711,8 +714,10 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
     // round 2 (53 / 57 / 61 us) and the tail of every launch runs at 2, then 1 wave per SIMD.  The class-major numbering
     // makes the strips of one round contiguous, and wave_cskew = 1000 a gives the rounds (1 + a), 1, (1 - a) times the
     // mean strip length so that all rounds finish together.  Rows are dealt by cumulative weight: no short last strip.
-    const int nbc = (g.tiles_x + 1) / 2, nb = g.nblocks, q = nb >> 3, r = nb & 7;
-    const int npairs = (S + 1) / 2;
+    // (the 1-pixel kernel: a workgroup is 4 wave-columns of ONE strip; the 2-pixel kernel: 2 wave-columns of 2 strips)
+    const int spw = g.strip == 3 ? 2 : 1;
+    const int nbc = g.strip == 3 ? (g.tiles_x + 1) / 2 : (g.tiles_x + 3) / 4, nb = g.nblocks, q = nb >> 3, r = nb & 7;
+    const int npairs = (S + spw - 1) / spw;
     int ncls = 0;
     std::vector<long> K;                       // K[k] = workgroups in rounds 0..k
     for (;; ++ncls) {
@@ -729,7 +734,7 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
       int k = 0;
       while (k < ncls - 1 && rank >= K[k]) ++k;
       const double wv = 1.0 + a_ * (mid - k) / (mid > 0 ? mid : 1.0);
-      for (int t = 0; t < 2 && 2 * sp + t < S; ++t) { wgt[2 * sp + t] = wv; total += wv; }
+      for (int t = 0; t < spw && spw * sp + t < S; ++t) { wgt[spw * sp + t] = wv; total += wv; }
     }
     double cum = 0;
     for (int k = 0; k < S; ++k) { b[k] = (int)((double)c->h * (cum / total) + 0.5); cum += wgt[k]; }
@@ -773,7 +778,7 @@ static int chain_flush(cvh_context *c)
   CvhStepArgs a;
   fill_args(c, &a, 0, 0);
   if (!a.chain) return fail(c, CVH_ERR_STATE, "chain-mode launches are pending but the context no longer selects chain mode");
-  HIPCHK(c, cvh_launch_chain_flush(a, c->stream));
+  HIPCHK(c, cvh_launch_chain_flush(a, c->C, c->stream));
   c->chain_pending = false;
   return CVH_OK;
 }
@@ -1066,8 +1071,24 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   // auto: the 2-pixel kernel for large planes (measured 50.4 vs 53.3 us/step at 4096^2, but 19 vs 15.7 at 2048^2:
   // its strips get too short there), the 1-pixel wave kernel otherwise
   const bool pm2_ok = c->w % 2 == 0 && c->w >= 128 && c->n < ((size_t)1 << 28);
-  const bool pm_wave2 = pm2_ok && (c->pm_kernel == 2 || (c->pm_kernel == -1 && c->n >= (size_t)12000000));
+  const bool pm_wave2 = pm2_ok && c->pm_kernel == 2;   // (was the default from 12 Mpixel on: 48.4 us/step at 4096^2; the 2-step kernel: 39.3)
+  // two time steps per launch (pm_wave_k2_kernel.hip): planes that fit the caches, where a step is launch / latency bound
+  const bool pm_k2 = !pm_wave2 && trips >= 2 && c->n < ((size_t)1 << 28) &&
+                     (c->pm_kernel == 3 || c->pm_kernel == -1);
   const bool pm_wave = !pm_wave2 && c->pm_kernel != 0;
+  CvhPmArgs a2 = a;      // geometry of the 2-step kernel (the odd last step runs the 1-step wave kernel)
+  if (pm_k2) {
+    a2.tiles_x = (c->w + cvh_pm_wave_k2_cols() - 1) / cvh_pm_wave_k2_cols();
+    int sr = c->pm_strip_rows;
+    if (sr <= 0) {
+      // ~51 strips whatever the size (measured, us/step: 1024^2: 16 rows 6.3, 24 rows 6.05, 32 rows 6.7; 2048^2: 16 13.0, 24 13.2,
+      // 32 13.3, 40 12.55, 48 13.5, 64 15.5; 4096^2: 48 40.1, 64 39.8, 80 38.2-39.3, 104 38.6, 128 41.9, 160 39.9, 200 44.6)
+      sr = (c->h + 50) / 51;
+      sr = ((sr + 4) / 8) * 8;   // nearest multiple of 8: the row loop is unrolled by 8
+      if (sr < 16) sr = 16;      // every strip pays 5 extra stage-1 rows
+    }
+    a2.strip_rows = sr;
+  }
   if (pm_wave2) {   // 2 pixels per lane: 124 output columns per wave, workgroup = 2 wave-columns x 2 strips
     a.tiles_x = (c->w + cvh_pm_wave2_cols() - 1) / cvh_pm_wave2_cols();
     int sr = c->pm_strip_rows;
@@ -1098,20 +1119,22 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   auto launch_pm = [&](const CvhPmArgs &pa) -> hipError_t {
     return kind == 2 ? cvh_launch_pm_wave2(pa, c->stream) : (kind == 1 ? cvh_launch_pm_wave(pa, c->stream) : cvh_launch_pm_step(pa, c->stream));
   };
+  const int per_launch = pm_k2 ? 2 : 1;   // time steps per launch of the bulk kernel
+  auto launch_bulk = [&](int from) -> hipError_t {
+    if (!pm_k2) { CvhPmArgs pa = a; pa.in = c->d_pm[from]; pa.out = c->d_pm[from ^ 1]; return launch_pm(pa); }
+    CvhPmArgs pa = a2; pa.in = c->d_pm[from]; pa.out = c->d_pm[from ^ 1];
+    return cvh_launch_pm_wave_k2(pa, c->stream);
+  };
   // kGraphSteps steps as one hipGraph, as for the CSV step: a graph node costs 1.6 us against 2.8 us for a stream launch
   // (tools/launch_probe.hip) and a 2048^2 step is only ~13 us.  The graph always starts from d_pm[0] (16 is even).
-  if (c->use_graph && trips >= kGraphSteps) {
-    CvhPmArgs key = a;
+  if (c->use_graph && trips >= kGraphSteps * per_launch) {
+    CvhPmArgs key = pm_k2 ? a2 : a;
     key.in = c->d_pm[0]; key.out = c->d_pm[1];
-    if (!c->pm_graph || c->pm_graph_kind != kind || memcmp(&key, &c->pm_graph_key, sizeof(key))) {
+    if (!c->pm_graph || c->pm_graph_kind != kind + 10 * pm_k2 || memcmp(&key, &c->pm_graph_key, sizeof(key))) {
       if (c->pm_graph) { (void)hipGraphExecDestroy(c->pm_graph); c->pm_graph = nullptr; }
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       hipError_t e = hipSuccess;
-      for (int t = 0; t < kGraphSteps && e == hipSuccess; ++t) {
-        CvhPmArgs pa = a;
-        pa.in = c->d_pm[t & 1]; pa.out = c->d_pm[(t & 1) ^ 1];
-        e = launch_pm(pa);
-      }
+      for (int t = 0; t < kGraphSteps && e == hipSuccess; ++t) e = launch_bulk(t & 1);
       hipGraph_t graph = nullptr;
       const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
       if (e != hipSuccess || e_end != hipSuccess || !graph) {
@@ -1121,7 +1144,7 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
       const hipError_t e_inst = hipGraphInstantiate(&c->pm_graph, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (e_inst != hipSuccess) { c->pm_graph = nullptr; return fail(c, CVH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e_inst)); }
-      c->pm_graph_key = key; c->pm_graph_kind = kind;
+      c->pm_graph_key = key; c->pm_graph_kind = kind + 10 * pm_k2;
     }
   }
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1129,8 +1152,9 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
     for (int k = 0; k < c->C; ++k) {
       HIPCHK(c, cvh_launch_pm_load(c->d_img[k], c->d_pm[0], c->n, c->stream));
       int cur = 0, t = 0;
-      for (; c->use_graph && c->pm_graph && trips - t >= kGraphSteps; t += kGraphSteps) HIPCHK(c, hipGraphLaunch(c->pm_graph, c->stream));
-      for (; t < trips; ++t) {
+      for (; c->use_graph && c->pm_graph && trips - t >= kGraphSteps * per_launch; t += kGraphSteps * per_launch) HIPCHK(c, hipGraphLaunch(c->pm_graph, c->stream));
+      for (; trips - t >= per_launch; t += per_launch) { HIPCHK(c, launch_bulk(cur)); cur ^= 1; }
+      for (; t < trips; ++t) {   // the odd last step of the 2-step flavour
         a.in = c->d_pm[cur]; a.out = c->d_pm[cur ^ 1];
         HIPCHK(c, launch_pm(a));
         cur ^= 1;

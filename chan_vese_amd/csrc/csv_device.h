@@ -188,14 +188,17 @@ __device__ void finalize(const CvhStepArgs &a, int is_init, double *sred, double
   if (tid < NS) sfin[tid] = total;
   __syncthreads();
   if (is_init && a.chain) {
-    // chain mode (csv_wave2_kernel.hip): seed the fixed-point sum set this step reads with the sums of the initial level
-    // set (centred: minus N/2 and sum(I)/2), all in shard 0, and clear the set the first launch adds into
-    const double centred[2] = {sfin[0] - 0.5 * a.npix, sfin[2] - 0.5 * a.sum_img[0]};
-    for (int i = tid; i < 4 * CVH_CHAIN_SHARDS; i += CVH_BLOCK) {
-      const int second = i >= 2 * CVH_CHAIN_SHARDS, j = i & (2 * CVH_CHAIN_SHARDS - 1), sum = j / CVH_CHAIN_SHARDS, shard = j % CVH_CHAIN_SHARDS;
+    // chain mode (chain_device.h): seed the fixed-point sum set this step reads with the sums of the initial level set
+    // (centred: minus N/2 and sum(I_k)/2), all in shard 0, and clear the set the first launch adds into
+    constexpr int SH = 64 / (1 + C);
+    for (int i = tid; i < 128; i += CVH_BLOCK) {
+      const int second = i >= 64, j = i & 63, sum = j / SH, shard = j % SH;
       long long v = 0;
-      if (!second && shard == 0) v = __double2ll_rn(centred[sum] * a.chain_scale[sum]);
-      a.chain->v[(a.chain_phase + second) & 3][sum][shard] = v;
+      if (!second && shard == 0) {
+        const double centred = sum == 0 ? sfin[0] - 0.5 * a.npix : sfin[1 + sum] - 0.5 * a.sum_img[sum - 1];
+        v = __double2ll_rn(centred * a.chain_scale[sum]);
+      }
+      a.chain->v[(a.chain_phase + second) & 3][j] = v;
     }
   }
   if (tid == 0) {

@@ -15,6 +15,7 @@
 #include "csv_device.h"
 #include "buffer_ops.h"
 #include "wave_math.h"
+#include "chain_device.h"
 #include <type_traits>
 
 using namespace cvh_dev;
@@ -49,84 +50,6 @@ __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, un
 __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
-}
-
-typedef const int __attribute__((address_space(4))) *const_int_p;   // read through the scalar (constant) cache: s_load
-
-// Sum of a 64-bit integer over each ROW of 16 lanes (DPP, exact: integer addition is associative).
-__device__ __forceinline__ long long row16_sum_i64(long long v)
-{
-  auto dpp = [](long long x, auto ctrl_tag) {
-    constexpr int ctrl = decltype(ctrl_tag)::value;
-    const int lo = __builtin_amdgcn_mov_dpp((int)x, ctrl, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp((int)(x >> 32), ctrl, 0xf, 0xf, true);
-    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x124>{});  // row_ror:4
-  v += dpp(v, std::integral_constant<int, 0x128>{});  // row_ror:8
-  return v;
-}
-__device__ __forceinline__ long long read_lane_i64(long long v, int l)
-{
-  const int lo = __builtin_amdgcn_readlane((int)v, l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
-  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
-// Chain mode: c1 / c2 of the level set this launch reads, from the fixed-point sums of set `set` (64 lanes = 2 sums x
-// 32 shards, one 8-byte load per lane).  Same formula as finalize(): nom / denom (src/main.cpp:280) with the centred
-// sums shifted back by N/2 and sum(I)/2, complements from the exact totals.
-__device__ __forceinline__ void chain_means(const CvhStepArgs &a, long long shard, double &c1, double &c2)
-{
-  const long long r = row16_sum_i64(shard);
-  const long long q0 = read_lane_i64(r, 0) + read_lane_i64(r, 16);
-  const long long q1 = read_lane_i64(r, 32) + read_lane_i64(r, 48);
-  const double sh = __builtin_fma((double)q0, a.chain_inv[0], 0.5 * a.npix);        // sum H
-  const double sih = __builtin_fma((double)q1, a.chain_inv[1], 0.5 * a.sum_img[0]); // sum I H
-  c1 = sih / sh;
-  c2 = (a.sum_img[0] - sih) / (a.npix - sh);
-}
-
-// Chain mode, the extra workgroup of every launch (and the whole of the flush kernel): books the iteration of the
-// PREVIOUS launch -- adds its per-workgroup sum u_diff^2 rows in a fixed order, norm, trace row, stop rule
-// (src/main.cpp:993-1000) -- off the critical path of the launch that runs beside it.  A stop found here means the
-// launch running now computes an iteration the reference never executes: its output goes to the other ping-pong
-// buffer and is never read (steps_done stays at the stopping iteration, later launches are no-ops).
-__device__ int chain_bookkeeping(const CvhStepArgs &a, bool flush, double c1_now, double c2_now, double *sred)
-{
-  const int tid = threadIdx.x;
-  CvhState *st = a.st;
-  const int pending = st->pending, t = st->steps_done;   // t = iterations booked so far = index of the pending launch
-  int stop_now = 0;
-  if (pending) {
-    const double *rows = a.chain_s4 + (size_t)((a.chain_pb + t) & 1) * a.nparts;
-    double acc[1] = {0.0};
-    for (int b = tid; b < a.nparts; b += CVH_BLOCK) acc[0] += rows[b];
-    const double total = block_reduce<1>(acc, sred);
-    if (tid == 0) {
-      const double nrm = sqrt(total);
-      if (a.trace && t < a.trace_cap) a.trace[(size_t)t * 3 + 2] = nrm;
-      st->norm = nrm;
-      st->steps_done = t + 1;
-      stop_now = nrm <= a.stop_cond;                    // src/main.cpp:1000, after the update
-      if (stop_now) st->stopped = 1;
-      if (a.host_status) {
-        __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-  const int tn = pending ? t + 1 : t;                   // iterations booked now = index of the launch running now
-  if (tid == 0) {
-    if (flush) {
-      st->pending = 0;
-    } else {
-      st->pending = stop_now ? 0 : 1;
-      if (!stop_now && a.trace && tn < a.trace_cap) { a.trace[(size_t)tn * 3] = c1_now; a.trace[(size_t)tn * 3 + 1] = c2_now; }
-    }
-  }
-  return tn;
 }
 
 template <bool FAST, int MINW>
@@ -189,21 +112,16 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   // region means of the level set this launch reads: from the fixed-point sum set (chain mode: one 8-byte load per
   // lane, in flight beside the first rows of u) or from the state block the last finaliser wrote
   double c1, c2;
-  long long chain_shard = 0;
-  if (chain) chain_shard = a.chain->v[a.chain_phase][lane >> 5][lane & 31];
+  long long chain_entry = 0;
+  if (chain) chain_entry = a.chain->v[a.chain_phase][lane];
   else { c1 = a.st->c1[0]; c2 = a.st->c2[0]; }
-  if (bookkeeper) {
-    if (wave == 0) a.chain->v[(a.chain_phase + 2) & 3][lane >> 5][lane & 31] = 0;   // the set the NEXT launch adds into
-    chain_means(a, chain_shard, c1, c2);
-    chain_bookkeeping(a, false, c1, c2, sred);
-    return;
-  }
+  if (bookkeeper) { chain_bookkeeper_block<1>(a, chain_entry, sred); return; }
   const double l1 = a.lambda1[0], l2 = a.lambda2[0];
   const double eps = a.eps, eps2 = eps * eps;
   const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_k[4], a.far_thr};
 
   auto fill_tables = [&]() {
-    if (chain) chain_means(a, chain_shard, c1, c2);
+    if (chain) { double m1[1], m2[1]; chain_means<1>(a, chain_entry, m1, m2); c1 = m1[0]; c2 = m2[0]; }
     if (FAST) {
       for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
       const double v = (double)tid;
@@ -466,31 +384,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   }
   const double total = block_reduce<NS>(acc, sred);
   if (chain) {
-    // the workgroup's sums of H - 1/2 and I (H - 1/2) as fixed-point integers into the set the next launch reads
-    // (shard by workgroup index: no queue on one address), its sum u_diff^2 as a row for the bookkeeper; nothing waits
-    CvhChainAcc *const ca = a.chain;
-    const int set = (a.chain_phase + 1) & 3, shard = (int)blockIdx.x & (CVH_CHAIN_SHARDS - 1);
-    if (tid == 0) __hip_atomic_fetch_add(&ca->v[set][0][shard], __double2ll_rn(total * a.chain_scale[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 2) __hip_atomic_fetch_add(&ca->v[set][1][shard], __double2ll_rn(total * a.chain_scale[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 4) a.chain_s4[(size_t)(a.chain_phase & 1) * a.nparts + blockIdx.x] = total;
+    chain_publish<1>(a, total);   // fixed-point atomics + the sum u_diff^2 row: nothing waits (chain_device.h)
   } else {
     publish_partials_and_maybe_finalize<1>(a, total, sred, sfin, s_last, a.nparts);
   }
   if (a.dbg_times && tid == 0) a.dbg_times[(size_t)a.nparts * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-}
-
-// Chain mode, at a host synchronisation point: books the last launch's iteration (nobody else will) and writes the
-// region means of the current level set into the state block.  One workgroup.
-__global__ __launch_bounds__(CVH_BLOCK) void csv_chain_flush_kernel(const CvhStepArgs a)
-{
-  __shared__ double sred[4];
-  const int lane = threadIdx.x & 63;
-  // sums of the level set after the last BOOKED iteration live in set (pb + steps_done); a stop found now leaves it there
-  const int done = chain_bookkeeping(a, true, 0.0, 0.0, sred);
-  const long long shard = a.chain->v[(a.chain_pb + done) & 3][lane >> 5][lane & 31];
-  double c1, c2;
-  chain_means(a, shard, c1, c2);
-  if (threadIdx.x == 0) { a.st->c1[0] = c1; a.st->c2[0] = c2; }   // region means of the current level set (cvh_get_means)
 }
 
 template <bool FAST, int MINW>
@@ -506,12 +404,6 @@ hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 }  // namespace
 
 int cvh_wave2_cols() { return W2; }
-
-hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, hipStream_t s)
-{
-  hipLaunchKernelGGL(csv_chain_flush_kernel, dim3(1), dim3(CVH_BLOCK), 0, s, a);
-  return hipGetLastError();
-}
 
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s)
 {

@@ -22,6 +22,7 @@
 #include "csv_device.h"
 #include "buffer_ops.h"
 #include "wave_math.h"
+#include "chain_device.h"
 #include <type_traits>
 
 using namespace cvh_dev;
@@ -64,24 +65,64 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
   double *slut = smem + L::off_lut;
   int *s_last = (int *)(smem + L::off_flag);
 
-  if (a.st->stopped) return;  // sticky stop: src/main.cpp:1000
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row arithmetic stays scalar
+  const bool chain = FAST && a.chain != nullptr;               // chain_device.h
+  const int h = a.h, w = a.w;
+
+  // ---- this wave's strip: workgroup = 4 adjacent wave-columns of one strip
+  const int nwc = a.tiles_x;           // wave-columns per image row
+  const int nbc = (nwc + 3) >> 2;      // workgroups per strip
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  wave_xcd:
+  // renumber them so that an XCD works on a contiguous run of workgroups (neighbouring wave-columns
+  // of the same strips): halo columns and shared image pieces then hit in that XCD's L2.
+  int bid = (int)blockIdx.x;
+  const bool bookkeeper = bid >= a.nparts;   // chain mode: one extra workgroup per launch
+  if (a.wave_xcd && !bookkeeper) {
+    const int nb = a.nparts, x = bid & 7, j = bid >> 3, q = nb >> 3, r = nb & 7;
+    if (a.wave_cls > 0) {   // class-major numbering by dispatch round (see csv_wave2_kernel.hip)
+      const int S = a.wave_cls, cl = j / S;
+      int rank = 0;
+      for (int xx = 0; xx < 8; ++xx) {
+        const int nx = q + (xx < r ? 1 : 0);
+        const int before = nx < cl * S ? nx : cl * S;
+        int mine = nx - cl * S;
+        mine = mine < 0 ? 0 : (mine > S ? S : mine);
+        rank += before + (xx < x ? mine : 0);
+      }
+      bid = rank + (j - cl * S);
+    } else {
+      bid = x * q + (x < r ? x : r) + j;
+    }
+  }
+  const int wc = (bid % nbc) * 4 + wave;
+  const int ws = bookkeeper ? 0 : (a.wave_rev ? a.tiles_y - 1 - bid / nbc : bid / nbc);
+  // one batch of scalar loads: the sticky stop flag (src/main.cpp:1000) and the strip's rows (the exit test reads all)
+  const const_int_p sb = (const_int_p)a.strip_bounds;
+  const int stopped = *(const_int_p)&a.st->stopped;
+  const int s0 = sb[ws], s1 = sb[ws + 1];
+  if ((stopped != 0) | (s1 < s0)) return;
+
   const unsigned long long t_start = a.dbg_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
   double *xs = smem + L::off_x + wave * L::wave_doubles;
-  const int h = a.h, w = a.w;
   if (tid == 0) *s_last = 0;
 
   double c1[C], c2[C], l1[C], l2[C];
+  long long chain_entry = 0;
+  if (chain) chain_entry = a.chain->v[a.chain_phase][lane];
 #pragma unroll
-  for (int k = 0; k < C; ++k) { c1[k] = a.st->c1[k]; c2[k] = a.st->c2[k]; l1[k] = a.lambda1[k]; l2[k] = a.lambda2[k]; }
+  for (int k = 0; k < C; ++k) {
+    if (!chain) { c1[k] = a.st->c1[k]; c2[k] = a.st->c2[k]; }
+    l1[k] = a.lambda1[k]; l2[k] = a.lambda2[k];
+  }
+  if (bookkeeper) { chain_bookkeeper_block<C>(a, chain_entry, sred); return; }
   const double eps = a.eps;
   const double eps2 = eps * eps;
   const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_k[4], a.far_thr};
 
   // the tables are filled while the first rows are in flight: see fill_tables() below
   auto fill_tables = [&]() {
+    if (chain) chain_means<C>(a, chain_entry, c1, c2);
     if (FAST) {
       for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
     }
@@ -101,25 +142,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0;
 
-  // ---- this wave's strip: workgroup = 4 adjacent wave-columns of one strip
-  const int nwc = a.tiles_x;           // wave-columns per image row
-  const int nbc = (nwc + 3) >> 2;      // workgroups per strip
-  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  wave_xcd:
-  // renumber them so that an XCD works on a contiguous run of workgroups (neighbouring wave-columns
-  // of the same strips): halo columns and shared image pieces then hit in that XCD's L2.
-  int bid = (int)blockIdx.x;
-  if (a.wave_xcd) {
-    const int nb = (int)gridDim.x, x = bid & 7, j = bid >> 3, q = nb >> 3, r = nb & 7;
-    bid = x * q + (x < r ? x : r) + j;
-  }
-  const int wc = (bid % nbc) * 4 + wave;
-  const int ws = a.wave_rev ? a.tiles_y - 1 - bid / nbc : bid / nbc;
-  const int s0 = a.strip_bounds[ws];
   const bool active = wc < nwc;        // the last workgroup of a strip may hold idle waves
   const int col = WCOLS * wc - 1 + lane;                // lane 0 = left halo column
   const bool lane_valid = active && (lane >= 1) && (col < w);
   if (active) {
-    const int s1 = a.strip_bounds[ws + 1];
     const int colc = clampi(col, 0, w - 1);
     const double fx = (col <= 0) ? 0.0 : 1.0;           // kappa_x(i,0) = 0 (:371)
     // Every vector-memory operation below is issued by ALL lanes on EVERY row (halo / out-of-
@@ -434,8 +460,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     __syncthreads();
   }
   if (!active && a.wave_sync) {                // idle waves still meet the per-iteration barrier
-    const int s1i = a.strip_bounds[ws + 1];
-    for (int ib = s0; ib < s1i; ib += R) __builtin_amdgcn_s_barrier();
+    for (int ib = s0; ib < s1; ib += R) __builtin_amdgcn_s_barrier();
   }
 
   if (a.dbg_times && lane == 0) {  // diagnostic stamps: only ever written to their own buffer
@@ -450,8 +475,9 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     d[3] = (unsigned long long)xcc | ((unsigned long long)hwid << 8);
   }
   const double total = block_reduce<NS>(acc, sred);
-  publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, s_last, gridDim.x);
-  if (a.dbg_times && tid == 0) a.dbg_times[(size_t)gridDim.x * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  if (chain) chain_publish<C>(a, total);   // fixed-point atomics + the sum u_diff^2 row: nothing waits (chain_device.h)
+  else publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, s_last, a.nparts);
+  if (a.dbg_times && tid == 0) a.dbg_times[(size_t)a.nparts * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int C, bool FAST, bool LUT, int MINW, int G>
@@ -469,8 +495,9 @@ hipError_t launch_wave_g(const CvhStepArgs &a, hipStream_t s)
     if (cap > lds) lds = cap;
   }
   const bool imgv = a.w % 16 == 0 && a.w >= 80 && a.wave_imgv;
-  if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
-  else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G>), dim3(a.nparts), dim3(CVH_BLOCK), lds, s, a);
+  const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup of chain mode
+  if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
+  else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
   return hipGetLastError();
 }
 

@@ -34,10 +34,11 @@ struct CvhState {
 // Chain mode of the 2-pixel wave kernel (csv_wave2_kernel.hip): the two sums the NEXT iteration needs, sum (H - 1/2)
 // and sum I (H - 1/2), are accumulated as 64-bit FIXED-POINT integers with agent-scope atomic adds -- integer addition
 // is associative, so the result is bitwise reproducible whatever the arrival order -- into one of four rotating sets
-// of 32 shards (same-address atomics serialise at ~10 ns each; 765 workgroups over 32 shards do not queue).  Launch e
+// of 16 or 32 shards per sum (same-address atomics serialise at ~10 ns each; 765 workgroups over 32 shards do not queue).  Launch e
 // reads set (e mod 4), adds into set (e+1 mod 4) and clears set (e+2 mod 4); nothing waits for a last workgroup.
-constexpr int CVH_CHAIN_SETS = 4, CVH_CHAIN_SHARDS = 32;
-struct CvhChainAcc { long long v[CVH_CHAIN_SETS][2][CVH_CHAIN_SHARDS]; };
+// A set holds 64 integers: (1 + C) sums x 64 / (1 + C) shards (chain_device.h).
+constexpr int CVH_CHAIN_SETS = 4;
+struct CvhChainAcc { long long v[CVH_CHAIN_SETS][64]; };
 
 // Sums carried per workgroup and reduced in a fixed order (deterministic):
 //   [0] sum H(u)  [1] sum (1-H(u))  [2..2+C) sum I_k H  [2+C..2+2C) sum I_k (1-H)  [2+2C] sum u_diff^2
@@ -87,7 +88,7 @@ struct CvhStepArgs {
   CvhChainAcc *chain;            // chain mode (2-pixel wave kernel, FAST): fixed-point sum sets, or null
   int chain_phase;               // set this launch reads
   int chain_pb;                  // set that held the sums of u when the run counter was last reset (flush: set = pb + steps_done)
-  double chain_scale[2], chain_inv[2];   // powers of two: fixed-point scale of sum (H-1/2) / sum I (H-1/2) and their inverses
+  double chain_scale[4], chain_inv[4];   // powers of two: fixed-point scale of sum (H-1/2), sum I_k (H-1/2) and their inverses
   double *chain_s4;              // [2][nparts] per-workgroup sum u_diff^2 rows, by launch parity
   int wave_cls;                  // 2-pixel wave kernel: workgroups per XCD per dispatch round (= CUs per XCD); > 0 numbers the
                                  // workgroups class-major (round 0 of every XCD first), 0 = plain XCD-contiguous numbering
@@ -116,7 +117,7 @@ hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStre
 hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave2_cols();
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s);
-hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, hipStream_t s);
+hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, int channels, hipStream_t s);
 hipError_t cvh_launch_wave(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave_cols();
 hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,
@@ -129,6 +130,8 @@ hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s);
 int cvh_pm_wave2_cols();
 hipError_t cvh_launch_pm_wave2(const CvhPmArgs &a, hipStream_t s);
 hipError_t cvh_launch_pm_wave(const CvhPmArgs &a, hipStream_t s);
+int cvh_pm_wave_k2_cols();
+hipError_t cvh_launch_pm_wave_k2(const CvhPmArgs &a, hipStream_t s);   // TWO time steps per launch
 int cvh_pm_wave_cols();
 hipError_t cvh_launch_pm_store(const double *state, uint8_t *plane, size_t n, hipStream_t s);
 void cvh_pm_grid(int h, int w, int *tiles_x, int *tiles_y);

@@ -101,8 +101,9 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
  *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
  *   "dma"            tile kernel: 1 = global->LDS DMA loader (slower on MI355X, default 0)
- *   "pm_kernel"      Perona-Malik data flow: -1 auto (2 from 12 Mpixel planes on, else 1), 0 LDS tile,
- *                    1 wave-streaming, 2 wave-streaming with 2 pixels per lane (even w >= 128)
+ *   "pm_kernel"      Perona-Malik data flow: -1 auto (= 3), 0 LDS tile,
+ *                    1 wave-streaming, 2 wave-streaming with 2 pixels per lane (even w >= 128),
+ *                    3 wave-streaming with TWO time steps per launch (an odd last step runs flavour 1)
  *   "pm_strip_rows"  Perona-Malik wave kernel: rows per strip (0 auto)
  * (Ablation / diagnostic knobs of the wave kernels are not part of this interface: they are listed in
  * chan_vese_amd/csrc/cvh_internal.h.)  Unknown keys and out-of-range values return CVH_ERR_ARG. */

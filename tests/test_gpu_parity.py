@@ -222,14 +222,16 @@ def test_enqueue_sync_interleaved_contexts(capi, oracle):
 
 
 @pytest.mark.parametrize("pm_opts", [dict(pm_kernel=2), dict(pm_kernel=2, pm_strip_rows=8), dict(pm_kernel=2, pm_strip_rows=20),
-                                     dict(pm_kernel=1), dict(pm_kernel=1, pm_strip_rows=8), dict(pm_kernel=0), dict()])
+                                     dict(pm_kernel=1), dict(pm_kernel=1, pm_strip_rows=8), dict(pm_kernel=0), dict(),
+                                     dict(pm_kernel=3), dict(pm_kernel=3, pm_strip_rows=8), dict(pm_kernel=3, pm_strip_rows=24)])
 @pytest.mark.parametrize("shape,K,L,T", [((40, 56), 30, 0.25, 5), ((64, 64), 10, 0.25, 20),
                                          ((37, 130), 1000, 0.1, 1.5), ((1, 50), 30, 0.25, 2),
                                          ((50, 1), 30, 0.25, 2), ((3, 3), 30, 0.2, 1),
                                          ((1, 128), 10, 0.25, 2), ((9, 248), 20, 0.25, 3), ((70, 372), 30, 0.25, 4)])
 def test_perona_malik_parity(capi, oracle, shape, K, L, T, pm_opts):
     """Every Perona-Malik data flow (tile, wave, wave with 2 pixels per lane: even widths >= 128, one or several
-    wave-columns of 124, exact and partial) against the oracle."""
+    wave-columns of 124, exact and partial; wave with TWO time steps per launch: even and odd trip counts, strips
+    shorter than / equal to / longer than the image) against the oracle."""
     h, w = shape
     rng = np.random.default_rng(11 + h + w)
     planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]

@@ -5,10 +5,11 @@ import os, sys
 sys.path.insert(0, '.')
 import numpy as np
 from chan_vese_amd import capi, synth
+C_ = int(os.environ.get("C", "1"))
 n = int(os.environ.get("N", "4096")); reps = int(os.environ.get("REPS", "3")); steps = int(os.environ.get("STEPS", "112"))
 settings = [dict((k, int(v)) for k, v in (kv.split("=") for kv in arg.split(","))) for arg in sys.argv[1:]]
-ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
-ctx.set_image([synth.disk(n)]); ctx.set_levelset(capi.checkerboard_host(n, n))
+ctx = capi.Context(n, n, C_, capi.make_params(tol=0.0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]) if C_ == 3 else capi.make_params(tol=0.0))
+ctx.set_image(synth.config_planes('C3', n) if C_ == 3 else [synth.disk(n)]); ctx.set_levelset(capi.checkerboard_host(n, n))
 ctx.enqueue_steps(400); ctx.sync()          # clocks up, far field everywhere
 keys = sorted({k for s in settings for k in s})
 res = np.zeros((len(settings), reps))

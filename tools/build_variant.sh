@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../chan_vese_amd/csrc"
 name=$1; shift
 mkdir -p variants/$name
 objs=""
-for f in api csv_kernels csv_strip_kernel csv_wave_kernel pm_kernels pm_wave2_kernel misc_kernels; do objs="$objs $f.o"; done
+for f in api csv_kernels csv_strip_kernel csv_wave_kernel pm_kernels pm_wave2_kernel pm_wave_k2_kernel chain_kernels misc_kernels; do objs="$objs $f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-function "$@" -c csv_wave2_kernel.hip -o variants/$name/csv_wave2_kernel.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o variants/$name/libchanvese_hip.so $objs variants/$name/csv_wave2_kernel.o
 echo built variants/$name
