@@ -1,12 +1,14 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for profiles/<name>/ on the GPU box:  tools/profile_round.sh <name>
 # (kernel-trace stats and PMC passes are separate runs; --pmc is never combined with trace domains)
-name=${1:-r01_final}
+# usage: tools/profile_round.sh <name> ["extra bench.py arguments"]     e.g.  tools/profile_round.sh r02_C3 "--config C3"
+name=${1:-r02_C2}
+ARGS=${2:-}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline"
+CMD="python3 bench.py $ARGS --steps 200 --warmup 10 --no-cpu-baseline --no-phases"
 # 1. un-profiled bench line
 ( cd $R && timeout -k 10 300 $CMD > $out/bench_default.json 2> $out/bench_default.err ) || echo "bench failed"
 # 2. kernel trace + stats
@@ -21,7 +23,7 @@ PY
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64"; do
   i=$((i+1)); rm -rf /tmp/pm_$i
-  ( cd $R && timeout -k 10 300 rocprofv3 --pmc $grp -d /tmp/pm_$i -o p --output-format csv -- python3 bench.py --steps 60 --warmup 40 --no-cpu-baseline > /tmp/pm_$i.log 2>&1 ) || { echo "pmc pass $i failed"; tail -3 /tmp/pm_$i.log; }
+  ( cd $R && timeout -k 10 300 rocprofv3 --pmc $grp -d /tmp/pm_$i -o p --output-format csv -- python3 bench.py $ARGS --steps 60 --warmup 40 --no-cpu-baseline --no-phases --prewarm-ms 0 > /tmp/pm_$i.log 2>&1 ) || { echo "pmc pass $i failed"; tail -3 /tmp/pm_$i.log; }
   f=$(find /tmp/pm_$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" "$out/pmc_summary.json" <<'PY'
 import csv, sys, json, collections
@@ -48,6 +50,6 @@ try:
 except Exception as e: print("no kernel stats", e)
 d = json.load(open(o + "/pmc_summary.json"))
 for kn, cs in d.items():
-    if "wave" in kn:
+    if "wave" in kn or "pm_" in kn:
         print(kn[:60], {k: round(v["per_launch"], 1) for k, v in cs.items()})
 PY
