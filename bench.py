@@ -173,7 +173,8 @@ def main():
                            "roofline": {"bound": "hbm", "achieved": pm_bytes * trips / (pm_ms / 1e3) / 1e9,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": pm_bytes * trips / (pm_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_launch": pm_bytes, "traffic": None}}
+                                        "algorithmic_bytes_per_launch": pm_bytes, "traffic": None,
+                                        "kernel": "pm_wave_k2_kernel (2 time steps per launch)", "steps_per_launch": 2}}
             ctx.set_levelset(u0)
             ctxs.append(ctx)
 
@@ -249,6 +250,9 @@ def main():
                 tj = json.load(open(tpath))
                 traffic = tj.get(f"csv_step_{n}x{n}x{C}")
                 traffic_source = tj.get("_source") if traffic is not None else None
+                if pm_info is not None and tj.get(f"pm_2steps_{n}x{n}x{C}") is not None:
+                    pm_info["roofline"]["traffic"] = tj[f"pm_2steps_{n}x{n}x{C}"] / 2.0   # per time step (a launch makes two)
+                    pm_info["roofline"]["traffic_source"] = tj.get("_source")
             except Exception:
                 traffic = None
         kopt = dict(kv.split("=") for kv in (args.opt or [])).get("kernel", "-1")
