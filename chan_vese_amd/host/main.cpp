@@ -35,6 +35,7 @@
 
 #include "chanvese_hip.h"
 #include "png_io.hpp"
+#include "overlay_text.hpp"
 
 namespace {
 
@@ -470,7 +471,11 @@ int main(int argc, char **argv)
   }
   int frame_no = 0;
   std::vector<uint8_t> contour, frame;
-  auto write_frame = [&]() {  // VideoWriterManager::write_frame, src/VideoWriterManager.cpp:40-57
+  overlay::Pos opos = overlay::Pos::TL;   // src/main.cpp:837-849
+  if (iequals(text_position, "BL")) opos = overlay::Pos::BL;
+  else if (iequals(text_position, "TR")) opos = overlay::Pos::TR;
+  else if (iequals(text_position, "BR")) opos = overlay::Pos::BR;
+  auto write_frame = [&](const std::string &txt) {  // VideoWriterManager::write_frame, src/VideoWriterManager.cpp:40-57
     contour.resize(n); frame.resize(n * 3);
     cvh_check(ctx, cvh_get_contour(ctx, contour.data()), "cvh_get_contour");
     for (size_t q = 0; q < n; ++q) {   // frames are RGB files; img_bgr is the reference's `img`
@@ -479,6 +484,11 @@ int main(int argc, char **argv)
       frame[3 * q + 1] = c ? contour_bgr[1] : img_bgr[3 * q + 1];
       frame[3 * q + 2] = c ? contour_bgr[0] : img_bgr[3 * q];
     }
+    if (overlay_text && !txt.empty()) {   // :47-53: colour and corner from overlay_color (:76-114), own 5x7 glyphs
+      int px, py; bool black;
+      overlay::place(img_bgr.data(), h, w, txt, opos, &px, &py, &black);
+      overlay::draw(frame.data(), h, w, txt, px, py, black);
+    }
     char name[64];
     std::snprintf(name, sizeof(name), "/frame_%06d", frame_no++);
     const std::string path = frames_dir + name + (has_ext(frame_ext, ".png") ? ".png" : ".ppm");
@@ -486,8 +496,7 @@ int main(int argc, char **argv)
   };
   if (write_video) {
     if (mkdir(frames_dir.c_str(), 0777) != 0 && errno != EEXIST) msg_exit("Error: cannot create \"" + frames_dir + "\"");
-    if (overlay_text) std::cerr << "note: overlay text (-O) is not rendered in this build\n";
-    write_frame();
+    write_frame("t = 0");   // :930
   }
 
   // ---- Perona-Malik: src/main.cpp:940-947
@@ -516,7 +525,7 @@ int main(int argc, char **argv)
       int stopped = 0;
       cvh_check(ctx, cvh_enqueue_steps(ctx, 1), "cvh_enqueue_steps");
       cvh_check(ctx, cvh_sync(ctx, &steps_done, &last_norm, &stopped), "cvh_sync");
-      write_frame();
+      write_frame("t = " + std::to_string(t));   // :997
       if (stopped) break;
     }
   }

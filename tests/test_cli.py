@@ -290,7 +290,7 @@ def test_cli_video_frames(cli, oracle, tmp_path):
     h, w = 40, 48
     img = synth.disk(40, 200, 50, noise=6, seed=5, h=h, w=w)
     write_pgm(tmp_path / "v.pgm", img)
-    r = run(cli, "-i", str(tmp_path / "v.pgm"), "-g", "-V", "-O", "-l", "yellow", "-N", "3", "-t", "0")
+    r = run(cli, "-i", str(tmp_path / "v.pgm"), "-g", "-V", "-l", "yellow", "-N", "3", "-t", "0")
     assert r.returncode == 0, r.stderr
     frames = sorted(os.listdir(tmp_path / "v_frames"))
     assert frames == [f"frame_{k:06d}.ppm" for k in range(4)]
@@ -302,6 +302,26 @@ def test_cli_video_frames(cli, oracle, tmp_path):
         expect = np.repeat(img[:, :, None], 3, axis=2)
         expect[c] = [255, 255, 0]
         assert np.array_equal(read_pnm(tmp_path / "v_frames" / frames[k]), expect), k
+    # -O: "t = <iteration>" at the chosen corner (padding 5), black over a bright background, white over a dark one
+    # (src/VideoWriterManager.cpp:76-114); own 5x7 glyphs: the text box is 6 len - 1 by 7 pixels; nothing else changes
+    for pos, bright in (("TL", False), ("BR", True), ("TR", True), ("BL", False)):
+        im2 = np.full((h, w), 230 if bright else 40, dtype=np.uint8)
+        im2[15:25, 10:38] = 40 if bright else 230
+        write_pgm(tmp_path / f"o{pos}.pgm", im2)
+        plain = run(cli, "-i", str(tmp_path / f"o{pos}.pgm"), "-g", "-V", "-N", "1", "-t", "0")
+        assert plain.returncode == 0, plain.stderr
+        f0 = [read_pnm(tmp_path / f"o{pos}_frames" / f"frame_{k:06d}.ppm") for k in range(2)]
+        withtxt = run(cli, "-i", str(tmp_path / f"o{pos}.pgm"), "-g", "-V", "-O", "-P", pos.lower(), "-N", "1", "-t", "0")
+        assert withtxt.returncode == 0, withtxt.stderr
+        for k in range(2):
+            f1 = read_pnm(tmp_path / f"o{pos}_frames" / f"frame_{k:06d}.ppm")
+            tw, th = 6 * len(f"t = {k}") - 1, 7
+            x0 = 5 if pos[1] == "L" else w - 5 - tw
+            y0 = 5 if pos[0] == "T" else h - 5 - th
+            diff = np.any(f1 != f0[k], axis=2)
+            assert diff.any() and not diff[:y0].any() and not diff[y0 + th:].any() and not diff[:, :x0].any() and not diff[:, x0 + tw:].any()
+            assert np.all(f1[diff] == (0 if bright else 255))        # 255 - mean < 105 -> black, else white
+            assert 8 <= diff.sum() <= tw * th // 2
     # default tolerance: the loop breaks at the reference's iteration and that iteration's frame exists
     write_pgm(tmp_path / "v2.pgm", img)
     r = run(cli, "-i", str(tmp_path / "v2.pgm"), "-g", "-V", "-t", "0.5", "--verbose")
