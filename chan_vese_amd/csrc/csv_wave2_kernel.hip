@@ -280,9 +280,14 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nya, ba, uda, Ia);
       const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, bb, udb, Ib);
       double hva, hvb;
+      // gfx950 hazard (found in round 2, tools/dbg_occ4b.py): under memory back-pressure a 16-byte buffer store reads its
+      // data registers long after it was issued -- a ds_read that re-used them right behind the store changed what lanes
+      // 12-15 of every row of 16 stored (sums right, stored u wrong, only from ~1024^2 on, only in the flavours whose
+      // register allocation happened to recycle the quad at once).  The stored pair therefore lives in keep[k] until the
+      // END of the group (4 rows, ~2000 cycles): the branch-free flavour needs it there anyway, the others pin it (below).
+      keep[k] = double2_t{va, vb};
       if (FAST && DEFER) {   // far-field form on every lane; near lanes are corrected once per group (no branch in a row)
         hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
-        keep[k] = double2_t{va, vb};
         near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
       } else if (FAST) {   // far/near decided per WAVE for both pixels (uniform branch)
         if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       } else {
         hva = heaviside_strict(va, eps); hvb = heaviside_strict(vb, eps);
       }
-      buf_store_f64x2(double2_t{va, vb}, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+      buf_store_f64x2(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {
         if (FAST) {
           acc[0] += hva; acc[0] += hvb;
@@ -356,6 +361,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
           }
         }
       }
+#pragma unroll
+      for (int k = 0; k < R; ++k) asm volatile("; row %2 of the group: store data still live" :: "v"(keep[k].x), "v"(keep[k].y), "n"(0));
       park(T, X, IQ);
     };
     const unsigned long long t_first = a.dbg_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // prologue done

@@ -245,3 +245,50 @@ def test_bench_gpus_2_gloo_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["ranks_in_group"] == 2 and d["data"] == "synthetic"
     assert d["config"]["images_total"] == 4 and len(d["config"]["per_rank_mpx_it_s"]) == 2
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_kernel_flavours_agree_at_4096(capi):
+    """Every CSV data flow / arithmetic flavour against the 1-pixel wave kernel at 4096^2, 3 iterations, GPU vs GPU.
+    Regression test for two gfx950 hazards found in round 2 that only showed under memory back-pressure (>= 1024^2) and only in
+    the flavours whose instruction schedule exposed them (csv_device.h dpp_safe_bits, csv_wave2_kernel.hip keep[]):
+    an FP64 result read by a DPP move two wait states later, and a 16-byte buffer store whose data registers were
+    re-used by an LDS read right behind it.  Stale values showed in lanes 12-15 of every row of 16."""
+    n = 4096
+    planes = [synth.disk(n)]
+    u0 = capi.checkerboard_host(n, n)
+
+    def run(opts):
+        with capi.Context(n, n, 1, capi.make_params(tol=0)) as ctx:
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.set_image(planes)
+            ctx.set_levelset(u0)
+            done, _ = ctx.run(3)
+            assert done == 3
+            return ctx.get_levelset()
+
+    ref_fast, ref_strict = run(dict(kernel=2)), run(dict(kernel=2, math_mode=1))
+    scale = np.abs(ref_fast).max()
+    assert np.abs(ref_fast - ref_strict).max() <= 1e-9 * scale
+    for opts, ref in ((dict(kernel=3), ref_fast), (dict(kernel=3, wave_occupancy=4), ref_fast), (dict(kernel=3, chain=0), ref_fast),
+                      (dict(kernel=3, strip_rows=100, wave_cls=0), ref_fast), (dict(kernel=3, math_mode=1), ref_strict),
+                      (dict(kernel=1), ref_fast), (dict(kernel=0), ref_fast), (dict(kernel=2, chain=0), ref_fast)):
+        d = np.abs(run(opts) - ref).max()
+        assert d <= 1e-9 * scale, (opts, d)
+
+
+def test_pm_flavours_agree_at_2048(capi):
+    """Perona-Malik data flows at 2048^2, STRICT arithmetic, 9 steps (odd: the 2-step kernel's last step runs the 1-step
+    kernel): uint8 planes identical across the tile, wave, 2-pixel wave (16-byte stores) and 2-step kernels."""
+    n = 2048
+    img = synth.config_planes("C4", n)
+    outs = {}
+    for pk in (0, 1, 2, 3):
+        with capi.Context(n, n, 1) as ctx:
+            ctx.set_option("math_mode", 1)
+            ctx.set_option("pm_kernel", pk)
+            ctx.set_image(img)
+            ctx.perona_malik(30.0, 0.25, 2.25)
+            outs[pk] = ctx.get_image()[0]
+    for pk in (0, 2, 3):
+        assert np.array_equal(outs[pk], outs[1]), pk
