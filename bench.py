@@ -179,11 +179,12 @@ def main():
             ctxs.append(ctx)
 
     def run_steps(k):
-        # interleave the images' streams in chunks so their kernels overlap on the GPU
-        chunk = 8 if len(ctxs) > 1 else 16   # 16 = one hipGraph of the library (api.hip, kGraphSteps)
-        done = 0
+        if len(ctxs) == 1:       # one image: the library issues k % 16 plain launches, then hipGraphs of 16 steps (api.hip)
+            ctxs[0].enqueue_steps(k)
+            return
+        done = 0                 # several images: interleave their streams in chunks of 8 so that their kernels overlap
         while done < k:
-            c = min(chunk, k - done)
+            c = min(8, k - done)
             for ctx in ctxs:
                 ctx.enqueue_steps(c)
             done += c
@@ -218,7 +219,7 @@ def main():
     run_steps(args.warmup)
     sync_all()
     for ctx in ctxs:
-        ctx.warm(min(steps, 8 if len(ctxs) > 1 else 16))   # hipGraph capture/instantiate is one-off host work: not a step
+        ctx.warm(steps if len(ctxs) == 1 else 8)   # hipGraph capture/instantiate is one-off host work: not a step
     barrier()
     sync_all()
     t0 = time.perf_counter()

@@ -825,8 +825,12 @@ static int warm_impl(cvh_context *c, long nsteps)
   const Geometry g = resolve_geometry(c);
   if (g.strip >= 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
   if (c->use_graph && nsteps >= kGraphSteps) {
-    // every graph launch of one run starts on the same ping-pong parity (kGraphSteps is even)
+    // every graph launch of one call starts on the same ping-pong parity / sum-set phase (kGraphSteps is a multiple of 4),
+    // after the nsteps % kGraphSteps plain launches that enqueue_impl() issues first
+    const int ahead = (int)(nsteps % kGraphSteps);
+    c->enqueued += ahead;
     const int rc = ensure_step_graph(c, (c->cur_base + c->enqueued) & 1);
+    c->enqueued -= ahead;
     if (rc != CVH_OK) return rc;
   }
   return CVH_OK;
@@ -838,8 +842,16 @@ static int enqueue_impl(cvh_context *c, int nsteps)
     const Geometry g = resolve_geometry(c);
     if (g.strip >= 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
   }
+  // The odd-sized part goes FIRST as plain launches: from an idle stream they reach the GPU within 3-5 us, while the first
+  // hipGraph replay takes 10-16 us; the graphs (runs of kGraphSteps) follow.  warm_impl() builds the graph for that position.
   int s = 0;
-  while (c->use_graph && nsteps - s >= kGraphSteps) {
+  const int plain = (c->use_graph && nsteps >= kGraphSteps) ? nsteps % kGraphSteps : nsteps;
+  for (; s < plain; ++s) {
+    const int rc = launch_one_step(c, (c->cur_base + c->enqueued) & 1, c->enqueued);
+    if (rc != CVH_OK) return rc;
+    c->enqueued++;
+  }
+  while (nsteps - s >= kGraphSteps) {
     const int parity = (c->cur_base + c->enqueued) & 1;
     const int rc = ensure_step_graph(c, parity);
     if (rc != CVH_OK) return rc;
@@ -847,11 +859,6 @@ static int enqueue_impl(cvh_context *c, int nsteps)
     if (c->graphs[parity].key[0].chain) c->chain_pending = true; else c->chain_acc_valid = false;
     c->enqueued += kGraphSteps;
     s += kGraphSteps;
-  }
-  for (; s < nsteps; ++s) {
-    const int rc = launch_one_step(c, (c->cur_base + c->enqueued) & 1, c->enqueued);
-    if (rc != CVH_OK) return rc;
-    c->enqueued++;
   }
   return CVH_OK;
 }
@@ -928,7 +935,7 @@ extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *l
   long remaining = max_steps < 0 ? (long)INT_MAX : (long)max_steps;  // src/main.cpp:890
   rc = prepare_host(c);  // one-off host work (src/main.cpp:950-959) stays outside the device timing
   if (rc != CVH_OK) return rc;
-  rc = warm_impl(c, remaining);  // so do the strip table and the graph instantiation
+  rc = warm_impl(c, remaining < c->sync_every ? remaining : (long)c->sync_every);  // so do the strip table and the graph of the first chunk
   if (rc != CVH_OK) return rc;
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   rc = prepare(c);
