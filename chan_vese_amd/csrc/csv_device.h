@@ -45,24 +45,10 @@ __device__ __forceinline__ double normalised(double up, double uc)
 // central difference as filter2D evaluates it: (-0.5)*a + 0.5*b (exactly 0.5*(b-a)).
 __device__ __forceinline__ double central(double a, double b) { return -0.5 * a + 0.5 * b; }
 
-// gfx950 hazard (found in round 2, tools/dbg_c1occ.py): an FP64 VALU result is written over several passes, and a DPP
-// (cross-lane) read issued only the 2 wait states later that hipcc guarantees picked up STALE values in lanes 12-15 of
-// every row of 16 -- in the kernel flavours where the scheduler happened to leave nothing else between a v_mul_f64 and the
-// v_mov_b32_dpp of its result (scattered wrong rows from 1024^2 on; the default flavour had 7 instructions in between).
-// Every DPP move of a double therefore reads a full-rate COPY: the copy is interlocked on the FP64 result like any
-// dependent VALU instruction, and the s_nop gives the copy -> DPP distance whatever the compiler does around the asm.
-__device__ __forceinline__ long long dpp_safe_bits(double v)
-{
-  const long long b = __double_as_longlong(v);
-  unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-  asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
-  return (long long)(((unsigned long long)hi << 32) | lo);
-}
-
 // value of `v` in lane-1; lane 0 of the wave receives `edge`.
 __device__ __forceinline__ double from_left_lane(double v, double edge)
 {
-  const long long vb = dpp_safe_bits(v), eb = __double_as_longlong(edge);
+  const long long vb = __double_as_longlong(v), eb = __double_as_longlong(edge);
   const int lo = __builtin_amdgcn_update_dpp((int)eb, (int)vb, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp((int)(eb >> 32), (int)(vb >> 32), 0x138, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
@@ -118,7 +104,7 @@ __device__ __forceinline__ double wave_sum(double v)
 {
   auto dpp = [](double x, auto ctrl_tag) {
     constexpr int ctrl = decltype(ctrl_tag)::value;
-    const long long b = dpp_safe_bits(x);
+    const long long b = __double_as_longlong(x);
     const int lo = __builtin_amdgcn_mov_dpp((int)b, ctrl, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), ctrl, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);

@@ -99,7 +99,7 @@ __device__ __forceinline__ double normalised4(double fwd, double bwd, double cen
 
 __device__ __forceinline__ double dpp_from_left(double v)
 {
-  const long long vb = dpp_safe_bits(v);   // see csv_device.h: FP64 result -> DPP read hazard
+  const long long vb = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_mov_dpp((int)vb, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
   const int hi = __builtin_amdgcn_mov_dpp((int)(vb >> 32), 0x138, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);

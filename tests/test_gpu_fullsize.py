@@ -249,10 +249,9 @@ def test_bench_gpus_2_gloo_on_one_gpu():
 
 def test_kernel_flavours_agree_at_4096(capi):
     """Every CSV data flow / arithmetic flavour against the 1-pixel wave kernel at 4096^2, 3 iterations, GPU vs GPU.
-    Regression test for two gfx950 hazards found in round 2 that only showed under memory back-pressure (>= 1024^2) and only in
-    the flavours whose instruction schedule exposed them (csv_device.h dpp_safe_bits, csv_wave2_kernel.hip keep[]):
-    an FP64 result read by a DPP move two wait states later, and a 16-byte buffer store whose data registers were
-    re-used by an LDS read right behind it.  Stale values showed in lanes 12-15 of every row of 16."""
+    Regression test for a gfx950 hazard found in round 2 that only showed under memory back-pressure (>= 1024^2) and only in
+    the flavours whose register allocation exposed it (csv_wave2_kernel.hip keep[]): a 16-byte buffer store whose data
+    registers were re-used by an LDS read right behind it stored stale values in lanes 12-15 of every row of 16."""
     n = 4096
     planes = [synth.disk(n)]
     u0 = capi.checkerboard_host(n, n)
