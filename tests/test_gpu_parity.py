@@ -175,6 +175,67 @@ def test_stop_rule_same_iteration(capi, oracle):
             assert rel_err(u_g, u_c) <= 1e-6
 
 
+@pytest.mark.parametrize("shape,channels,kernel", [((64, 160), 1, 3), ((64, 160), 1, 2), ((48, 100), 3, 2), ((700, 1008), 1, 3)])
+def test_chain_mode_stop_edges(capi, oracle, shape, channels, kernel):
+    """Chain mode books an iteration one launch late (chain_device.h): the stop iteration, the level set, the trace and the
+    region means must still be the reference's when the stop fires at the FIRST iteration, at the last enqueued one, in the
+    middle of a hipGraph, and a run / an enqueue chain must continue correctly afterwards."""
+    h, w = shape
+    rng = np.random.default_rng(h + w + channels)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(channels)]
+    u0 = oracle.checkerboard(h, w)
+    lam = dict(lambda1=[1, 0.8, 0.5], lambda2=[0.7, 0.5, 1]) if channels == 3 else {}
+    # norms of the free run decide the tolerances that stop at chosen iterations
+    _, _, _, tr = oracle.csv_run(planes, u0, oracle.make_params(tol=0, **lam), 24)
+    base = oracle.stop_condition(planes, 1.0)
+    for stop_at in (1, 2, 17, 24):
+        # the first iteration whose norm is <= tol * base must be `stop_at`: pick tol just above that norm
+        norms = tr[:, -1]
+        tol = float(norms[stop_at - 1] / base * (1 + 1e-9))
+        if np.any(norms[:stop_at - 1] <= tol * base):
+            continue          # an earlier iteration already has a smaller norm: this stop point cannot be isolated
+        pk = dict(tol=tol, **lam)
+        u_c, done_c, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), 40)
+        assert done_c == stop_at
+        for mode in ("run", "enqueue"):
+            with capi.Context(h, w, channels, capi.make_params(**pk)) as ctx:
+                ctx.set_option("kernel", kernel)
+                ctx.set_option("trace", 64)
+                ctx.set_image(planes)
+                ctx.set_levelset(u0)
+                if mode == "run":
+                    done, nrm = ctx.run(40)
+                else:
+                    ctx.enqueue_steps(19); ctx.enqueue_steps(21)
+                    done, nrm, stopped = ctx.sync()
+                    assert stopped
+                assert done == stop_at, (mode, stop_at, done)
+                assert nrm == pytest.approx(nrm_c, rel=1e-9)
+                u_g = ctx.get_levelset()
+                assert rel_err(u_g, u_c) <= 1e-9
+                assert np.allclose(ctx.get_trace(64), tr_c, rtol=1e-9, atol=0)
+                c1g, c2g = ctx.get_means()
+                c1c = [oracle.region_mean(p, u_c, 0) for p in planes]
+                c2c = [oracle.region_mean(p, u_c, 1) for p in planes]
+                assert np.allclose(c1g, c1c, rtol=1e-9) and np.allclose(c2g, c2c, rtol=1e-9)
+                # continuation: a new run from the stopped state with tol 0 matches the oracle's continuation
+                ctx.set_params(capi.make_params(tol=0, **lam))
+                done2, _ = ctx.run(3)
+                assert done2 == 3
+                u_c2, _, _, _ = oracle.csv_run(planes, u_c, oracle.make_params(tol=0, **lam), 3)
+                assert rel_err(ctx.get_levelset(), u_c2) <= 1e-9
+    # zero and one step, no stop
+    with capi.Context(h, w, channels, capi.make_params(tol=0, **lam)) as ctx:
+        ctx.set_option("kernel", kernel)
+        ctx.set_image(planes)
+        ctx.set_levelset(u0)
+        assert ctx.run(0)[0] == 0 and np.array_equal(ctx.get_levelset(), u0)
+        assert ctx.run(1)[0] == 1
+        u1 = u0.copy()
+        oracle.csv_step(planes, u1, oracle.make_params(tol=0, **lam))
+        assert rel_err(ctx.get_levelset(), u1) <= 1e-12
+
+
 def test_unlimited_steps_runs_to_stop(capi, oracle):
     img = synth.disk(96, 220, 30)
     u0 = oracle.checkerboard(96, 96)
