@@ -17,14 +17,14 @@ __global__ __launch_bounds__(256) void pass_k(const double2_t *__restrict__ in, 
   for (; i < n2; i += stride) {
     const bool tail = i >= keep2;
     double2_t v;
-    if (tail && (MODE == 1 || MODE == 2)) v = __builtin_nontemporal_load(&in[i]); else v = in[i];
+    if (tail && (MODE == 1 || MODE == 2 || MODE == 4)) v = __builtin_nontemporal_load(&in[i]); else v = in[i];
     if ((i & 7) == 0) {
       u32x4_t b;
       if (tail && (MODE == 1 || MODE == 2)) b = __builtin_nontemporal_load(&img[i >> 3]); else b = img[i >> 3];
       v.x += (double)(b.x & 1) * 1e-30;
     }
     v.x += add; v.y += add;
-    if (tail && (MODE == 1 || MODE == 3)) __builtin_nontemporal_store(v, &out[i]); else out[i] = v;
+    if (tail && (MODE == 1 || MODE == 3 || MODE == 4)) __builtin_nontemporal_store(v, &out[i]); else out[i] = v;
   }
 }
 
@@ -37,7 +37,7 @@ int main(int argc, char **argv)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int grid = 256 * 8, blk = 256, iters = 100;
   const double keeps[] = {1.0, 0.0, 0.25, 0.5, 0.625, 0.75, 0.85, 0.92};
-  for (int mode = 0; mode < 4; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     for (double keep : keeps) {
       if (mode == 0 && keep != 1.0) continue;
       if (mode != 0 && keep == 1.0) continue;
@@ -50,6 +50,7 @@ int main(int argc, char **argv)
           if (mode == 0) hipLaunchKernelGGL(pass_k<0>, dim3(grid), dim3(blk), 0, 0, src, dst, img, n2, keep2, 1.0);
           else if (mode == 1) hipLaunchKernelGGL(pass_k<1>, dim3(grid), dim3(blk), 0, 0, src, dst, img, n2, keep2, 1.0);
           else if (mode == 2) hipLaunchKernelGGL(pass_k<2>, dim3(grid), dim3(blk), 0, 0, src, dst, img, n2, keep2, 1.0);
+          else if (mode == 4) hipLaunchKernelGGL(pass_k<4>, dim3(grid), dim3(blk), 0, 0, src, dst, img, n2, keep2, 1.0);
           else hipLaunchKernelGGL(pass_k<3>, dim3(grid), dim3(blk), 0, 0, src, dst, img, n2, keep2, 1.0);
         }
         hipEventRecord(e1); hipEventSynchronize(e1);
@@ -58,7 +59,7 @@ int main(int argc, char **argv)
       }
       const double us = best * 1e3 / iters, bytes = 16.0 * n + n;
       printf("mode %d (%s) keep %.3f: %.2f us per pass, %.2f TB/s\n", mode,
-             mode == 0 ? "all default" : mode == 1 ? "tail nt load+store" : mode == 2 ? "tail nt load" : "tail nt store", keep, us, bytes / us / 1e6);
+             mode == 0 ? "all default" : mode == 1 ? "tail nt load+store" : mode == 2 ? "tail nt load" : mode == 3 ? "tail nt store" : "tail nt u, image default", keep, us, bytes / us / 1e6);
       fflush(stdout);
     }
   }
