@@ -43,13 +43,23 @@ struct Wave2Smem {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// (-DCVH_ABLATE_MEMORY / -DCVH_ABLATE_COMPUTE: diagnostic builds, results wrong by design -- see buffer_ops.h)
 __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
+#ifdef CVH_ABLATE_MEMORY
+  const double v = __builtin_bit_cast(double, 0x4059000000000000ull | (unsigned long long)((voff + soff) & 0xffff));   // ~100: far field
+  return double2_t{v, -v};
+#else
   return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+#endif
 }
 __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
+#ifndef CVH_ABLATE_MEMORY
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+#else
+  asm volatile("" :: "v"(v.x), "v"(v.y));
+#endif
 }
 
 template <bool FAST, int MINW>
@@ -272,6 +282,16 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       const double2_t up = x_own[k * (XP2 / 2)];
       const double uw_n = x_w[k * XP2], ue_n = x_e[k * XP2];
       const int ba = im[k] & 0xff, bb = (im[k] >> 8) & 0xff;
+#ifdef CVH_ABLATE_COMPUTE
+      {   // keeps every load, LDS exchange and the store; no arithmetic
+        keep[k] = double2_t{u0.x + (up.x + um.x + uw) * 1e-30 + (double)ba * 1e-30, u0.y + (up.y + um.y + ue) * 1e-30 + (double)bb * 1e-30};
+        near_mask[k] = 0ull;
+        buf_store_f64x2(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+        acc[0] += keep[k].x; acc[4] += 1.0;   // a non-zero norm: the stop rule must not fire
+        um = u0; u0 = up; uw = uw_n; ue = ue_n;
+        return;
+      }
+#endif
       // x-gradients first: nx(b) is the west gradient of lane+1's a (DPP), nx(a) the west gradient of b
       const double nxa = norm(u0.y, uw, u0.x);       // east = own b, west = lane-1's b
       const double nxb = norm(ue, u0.x, u0.y);       // east = lane+1's a, west = own a
