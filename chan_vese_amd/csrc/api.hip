@@ -22,7 +22,6 @@ struct cvh_context {
   uint8_t *d_img[CVH_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
   double *d_u[2] = {nullptr, nullptr};
   void *d_u_slab = nullptr;
-  size_t u_skew = 0;            // bytes (multiple of 256) between the two level-set buffers beyond a 2 MiB multiple
   CvhState *d_state = nullptr;
   CvhState *h_state = nullptr;  // pinned, four slots for pipelined polling
   double *d_partials = nullptr;
@@ -176,16 +175,12 @@ static int create_impl(cvh_context *c)
   // 64 doubles of slack behind each level-set buffer: the wave kernel parks the stores of lanes
   // that own no pixel there (see csv_wave_kernel.hip)
   {
-    // one slab for the ping-pong pair; the second buffer starts `u_skew` bytes past a 2 MiB boundary so that row r of the
-    // buffer being read and row r of the buffer being written do not map to the same memory channels at the same time
-    // (hipMalloc blocks are 2 MiB aligned: two separate allocations are congruent modulo every interleave period)
+    // one slab for the ping-pong pair (64 doubles of slack behind each buffer: the wave kernels park the stores of lanes
+    // that own no pixel there).  Skewing the second buffer against the first by 256 B .. 1 MiB was measured: no effect.
     const size_t each = (((c->n + 64) * sizeof(double)) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-    size_t skew = c->u_skew;
-    if (const char *e = getenv("CVH_U_SKEW")) skew = (size_t)strtoul(e, nullptr, 0);
-    skew &= ~(size_t)255;
-    HIPCHK(c, hipMalloc((void **)&c->d_u_slab, 2 * each + skew + 256));
+    HIPCHK(c, hipMalloc((void **)&c->d_u_slab, 2 * each));
     c->d_u[0] = (double *)c->d_u_slab;
-    c->d_u[1] = (double *)((char *)c->d_u_slab + each + skew);
+    c->d_u[1] = (double *)((char *)c->d_u_slab + each);
   }
   HIPCHK(c, hipMalloc((void **)&c->d_state, sizeof(CvhState)));
   HIPCHK(c, hipMemset(c->d_state, 0, sizeof(CvhState)));

@@ -14,8 +14,9 @@
 //   "wave_depth" rows per group (4, 8), "wave_prio" s_setprio progress equalisation (0 off, 1 quarters,
 //   2-4 thresholds crowded to the end, 5 clock-paced), "wave_sync" workgroup barrier per group (1),
 //   "wave_imgv" 16-byte image pieces (1), "wave_xcd" XCD-contiguous workgroup numbering (1),
-//   "wave_skew" per-mille strip-length skew (0), "wave_cls" class-major numbering of the 2-pixel kernel (1),
-//   "wave_cskew" per-mille strip-length skew between dispatch rounds (kernel 3), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
+//   "wave_skew" per-mille strip-length skew of the 1-pixel kernel (0), "wave_cls" class-major workgroup numbering (0 off,
+//   1 = 2-pixel kernel (default), 2 = 1-pixel kernel too), "wave_cskew" per-mille strip-length skew between dispatch rounds (500),
+//   "chain" fixed-point chained sums + deferred bookkeeping in the wave kernels (1), "far_terms" terms of the far-field series (5; 4), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
 //   read with cvh_debug_read, tools/wave_timeline.py).
 
 // Device-resident scalar state of one context.  Written only by the finalising workgroup
