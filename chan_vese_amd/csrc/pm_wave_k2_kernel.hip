@@ -3,11 +3,11 @@
 // perona_malik (src/main.cpp:478-560) is `trips` dependent sweeps over a plane; at 2048^2 one sweep moves 64 MiB and takes
 // ~14 us of kernel time, much of it per-launch (prologue, pipeline fill, tail).  Here a wave marches down its strip ONCE and
 // carries two pipeline stages: stage 1 turns rows of I(t) into rows of I(t+1) exactly as pm_wave_kernel does (same
-// arithmetic, same order of operations: STRICT stays bit-exact), stage 2 follows 3 rows behind and turns those rows -- taken
+// arithmetic, same order of operations: STRICT stays bit-exact), stage 2 follows 4 rows behind and turns those rows -- taken
 // from registers, never written to memory -- into rows of I(t+2).  Half the launches, half the HBM/L2 traffic per step.
 //
 //   lane  <->  column 56 wc - 4 + lane : 4 halo columns on either side (2 per stage), 56 output columns per wave
-//   stage 1 rows [s0 - 2, s1 + 2), stage 2 rows [s0, s1)          (the 5 extra stage-1 rows are the price per strip)
+//   stage 1 rows [s0 - 2, s1 + 3), stage 2 rows [s0, s1), 4 rows behind   (the 6 extra stage-1 rows are the price per strip)
 //   x-neighbours of I and of g go through per-wave LDS row slots, one set per stage; g(i-1..i+1) of the own column and the
 //   own column of I (8-row ring for stage 1: 4 rows live + 4 loads in flight; 5 live rows for stage 2) stay in registers.
 // Border rules (src/main.cpp:518-519, :527-530): g == 1 on the image's border ring (from the GLOBAL row / column, the same
@@ -94,22 +94,27 @@ __global__ __launch_bounds__(CVH_BLOCK, 4) void pm_wave_k2_kernel(const CvhPmArg
     S.gw = sG[2 * 64 + lw]; S.ge = sG[2 * 64 + le];
   };
 
-  // One row of one stage: produces row i (ring phase k = (i - base) & 7, compile-time after unrolling).  S.q must hold
-  // rows i-1 .. i+3.  Returns I_next(i, own column); pm_wave_kernel's loop body (pm_kernels.hip), stage-agnostic.
-  auto stage_row = [&](PmStage &S, double *sI, double *sG, int lw, int le, int k, int i, bool second) -> double {
+  // One row of one stage, in two halves around ONE wave-level LDS fence.  `stage_publish` writes row i+3 of the own column
+  // and g(i+1) into the stage's LDS slots (ring phase k = (i - base) & 7, compile-time after unrolling; S.q must hold rows
+  // i-1 .. i+3); `stage_finish` reads their x-neighbours back and produces I_next(i, own column) -- pm_wave_kernel's loop body
+  // (pm_kernels.hip), stage-agnostic.  The two stages of an iteration are independent of each other (stage 2 consumes what
+  // stage 1 produced in the PREVIOUS iteration), so both publish, ONE fence follows, both finish: one LDS round trip per
+  // iteration instead of two, and twice the independent arithmetic around it.
+  auto stage_publish = [&](PmStage &S, double *sI, double *sG, int k, int i, double &gnew) {
+    const double I0 = S.q[(k + 2) & 7], Ipp = S.q[(k + 4) & 7];
+    sI[((k + 1) & 3) * 64 + lane] = S.q[(k + 5) & 7];   // publish row i+3, its neighbours are fetched after the fence
+    gnew = g_of(S.nw[(k + 2) & 3], I0, S.ne[(k + 2) & 3], S.nw[(k + 3) & 3], S.ne[(k + 3) & 3],
+                S.nw[(k + 0) & 3], Ipp, S.ne[(k + 0) & 3], i + 1);
+    sG[((k + 3) & 3) * 64 + lane] = gnew;
+  };
+  auto stage_finish = [&](PmStage &S, double *sI, double *sG, int lw, int le, int k, int i, bool second, double gnew) -> double {
     double Im = S.q[(k + 1) & 7];
     const double I0 = S.q[(k + 2) & 7];
     double Ip = S.q[(k + 3) & 7];
-    const double Ipp = S.q[(k + 4) & 7];
     if (second) {                            // rows of I(t+1) outside the image: index clamp (:527-530), wave-uniform
       if (i <= 0) Im = I0;
       if (i >= h - 1) Ip = I0;
     }
-    sI[((k + 1) & 3) * 64 + lane] = S.q[(k + 5) & 7];   // publish row i+3, fetch its neighbours (used from the next row on)
-    const double gnew = g_of(S.nw[(k + 2) & 3], I0, S.ne[(k + 2) & 3], S.nw[(k + 3) & 3], S.ne[(k + 3) & 3],
-                             S.nw[(k + 0) & 3], Ipp, S.ne[(k + 0) & 3], i + 1);
-    sG[((k + 3) & 3) * 64 + lane] = gnew;
-    fence();
     const double nw_n = sI[((k + 1) & 3) * 64 + lw], ne_n = sI[((k + 1) & 3) * 64 + le];
     const double gw_n = sG[((k + 3) & 3) * 64 + lw], ge_n = sG[((k + 3) & 3) * 64 + le];
     const double cn = S.gr[(k + 1) & 3], c0 = S.gr[(k + 2) & 3], cs = gnew;
@@ -130,6 +135,12 @@ __global__ __launch_bounds__(CVH_BLOCK, 4) void pm_wave_k2_kernel(const CvhPmArg
     S.gw = gw_n; S.ge = ge_n;                              // g(i+1, col -/+ 1) for the next row
     return outv;
   };
+  auto stage_row = [&](PmStage &S, double *sI, double *sG, int lw, int le, int k, int i, bool second) -> double {
+    double gnew;
+    stage_publish(S, sI, sG, k, i, gnew);
+    fence();
+    return stage_finish(S, sI, sG, lw, le, k, i, second, gnew);
+  };
 
   PmStage A, B;
   const int base1 = s0 - 2;                  // first row stage 1 produces
@@ -138,25 +149,32 @@ __global__ __launch_bounds__(CVH_BLOCK, 4) void pm_wave_k2_kernel(const CvhPmArg
   for (int j = 0; j < 8; ++j) A.q[j] = LD(base1 - 2 + j);
   stage_prologue(A, sI1, sG1, lw1, le1, base1);
   A.q[0] = LD(base1 + 6);
-  // ---- stage 1 alone for 5 rows: I(t+1) rows s0-2 .. s0+2 = stage 2's ring slots 0..4
+  // ---- stage 1 alone for 6 rows: I(t+1) rows s0-2 .. s0+2 = stage 2's ring slots 0..4, row s0+3 waits in v1
+  double v1 = 0.0;
 #pragma unroll
-  for (int t = 0; t < 5; ++t) {
+  for (int t = 0; t < 6; ++t) {
     const int i1 = base1 + t;
-    B.q[t] = stage_row(A, sI1, sG1, lw1, le1, t & 7, i1, false);
+    const double o = stage_row(A, sI1, sG1, lw1, le1, t & 7, i1, false);
+    if (t < 5) B.q[t] = o; else v1 = o;
     A.q[(t + 1) & 7] = LD(i1 + 7);           // row i1-1 is dead: its slot takes row i1+7
   }
   B.q[5] = 0.0; B.q[6] = 0.0; B.q[7] = 0.0;
   stage_prologue(B, sI2, sG2, lw2, le2, s0);
-  // ---- both stages: stage 1 produces row s0+3+j while stage 2 produces row s0+j
+  // ---- both stages: stage 2 produces row s0+j from what stage 1 produced up to the PREVIOUS iteration (v1 = row s0+j+3),
+  // stage 1 produces row s0+j+4
   for (int jb = 0; jb < rows; jb += 8) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const int i2 = s0 + jb + kk, i1 = i2 + 3;
-      const int k1 = (5 + kk) & 7, k2 = kk;
-      const double v1 = stage_row(A, sI1, sG1, lw1, le1, k1, i1, false);
-      A.q[(k1 + 1) & 7] = LD(i1 + 7);
+      const int i2 = s0 + jb + kk, i1 = i2 + 4;
+      const int k1 = (6 + kk) & 7, k2 = kk;
       B.q[(k2 + 5) & 7] = v1;                // row i2+3 of I(t+1)
-      const double v2 = stage_row(B, sI2, sG2, lw2, le2, k2, i2, true);
+      double g1, g2;
+      stage_publish(A, sI1, sG1, k1, i1, g1);
+      stage_publish(B, sI2, sG2, k2, i2, g2);
+      fence();
+      v1 = stage_finish(A, sI1, sG1, lw1, le1, k1, i1, false, g1);
+      A.q[(k1 + 1) & 7] = LD(i1 + 7);
+      const double v2 = stage_finish(B, sI2, sG2, lw2, le2, k2, i2, true, g2);
       // lanes without an output column are dropped by the hardware (offset beyond the buffer), rows past the strip
       // end by an empty resource
       buf_store_f64(v2, i2 < s1 ? rout : make_rsrc(a.out, 0u), voff_st, (unsigned)i2 * rowbytes);
