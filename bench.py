@@ -67,7 +67,7 @@ def parse(argv=None):
     ap.add_argument("--no-phases", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--pm-steps", type=int, default=1000, help="C4: Perona-Malik steps (T = steps * 0.25)")
-    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="device clock warm-up before the W warm-up steps: this many ms of the same kernel on a SCRATCH "
                          "context (own buffers; the measured level sets are not touched). 0 = off")
     return ap.parse_args(argv)
