@@ -699,24 +699,23 @@ static int prepare(cvh_context *c)
 // equal strips then finish up to 10 us apart inside one SIMD (tools/wave_timeline.py) -- the tail
 // runs at 1-2 waves per SIMD.  wave_skew = 1000 alpha makes the strip length fall linearly from
 // (1 + alpha) to (1 - alpha) times the mean with the strip index, so they finish together.
-static int upload_strip_bounds(cvh_context *c, const Geometry &g)
+// First row of every strip of the wave kernels, b[0 .. S] (pure host arithmetic: also exported for the CPU tests).
+//   kind 3: 2-pixel kernel (a workgroup is 2 wave-columns of 2 strips), kind 2: 1-pixel kernel (4 wave-columns of ONE strip)
+//   cls > 0: class-major workgroup numbering with `cls` workgroups per XCD per dispatch round; cskew = per-mille skew between rounds
+//   cls == 0: equal strips of strip_rows rows (skew: the 1-pixel kernel's legacy linear skew)
+static void compute_strip_bounds(int kind, int h, int tiles_x, int S, int strip_rows, int nblocks, int cls, int cskew, int skew,
+                                 std::vector<int> &b)
 {
-  const int cls = (((g.strip == 3 && c->wave_cls) || (g.strip == 2 && c->wave_cls == 2)) && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
-  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip, c->h};
-  if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
-  const int S = g.tiles_y;
-  std::vector<int> b((size_t)S + 1);
+  b.assign((size_t)S + 1, 0);
   if (cls) {
-    // 2-pixel kernel, class-major numbering (csv_wave2_kernel.hip): the hardware deals workgroup b to XCD b % 8 and,
-    // inside an XCD, the first `cls` workgroups to distinct CUs, the next `cls` to the same CUs again, ... (measured,
-    // tools/wave_timeline.py: a CU holds workgroups j, j + 32, j + 64 of its XCD, in wave slots 0, 1, 2).  At equal
-    // priority the SIMD arbiter serves the OLDEST wave first, so round 0 finishes 4 us before round 1 and 8 us before
-    // round 2 (53 / 57 / 61 us) and the tail of every launch runs at 2, then 1 wave per SIMD.  The class-major numbering
-    // makes the strips of one round contiguous, and wave_cskew = 1000 a gives the rounds (1 + a), 1, (1 - a) times the
-    // mean strip length so that all rounds finish together.  Rows are dealt by cumulative weight: no short last strip.
-    // (the 1-pixel kernel: a workgroup is 4 wave-columns of ONE strip; the 2-pixel kernel: 2 wave-columns of 2 strips)
-    const int spw = g.strip == 3 ? 2 : 1;
-    const int nbc = g.strip == 3 ? (g.tiles_x + 1) / 2 : (g.tiles_x + 3) / 4, nb = g.nblocks, q = nb >> 3, r = nb & 7;
+    // Class-major numbering (csv_wave2_kernel.hip): the hardware deals workgroup b to XCD b % 8 and, inside an XCD, the first
+    // `cls` workgroups to distinct CUs, the next `cls` to the same CUs again, ... (measured, tools/wave_timeline.py: a CU holds
+    // workgroups j, j + 32, j + 64 of its XCD, in wave slots 0, 1, 2).  At equal priority the SIMD arbiter serves the OLDEST
+    // wave first, so round 0 finishes 4 us before round 1 and 8 us before round 2 (53 / 57 / 61 us) and the tail of every launch
+    // runs at 2, then 1 wave per SIMD.  The class-major numbering makes the strips of one round contiguous, and cskew = 1000 a
+    // gives the rounds (1 + a), 1, (1 - a) times the mean strip length.  Rows are dealt by cumulative weight: no short last strip.
+    const int spw = kind == 3 ? 2 : 1;
+    const int nbc = kind == 3 ? (tiles_x + 1) / 2 : (tiles_x + 3) / 4, nb = nblocks, q = nb >> 3, r = nb & 7;
     const int npairs = (S + spw - 1) / spw;
     int ncls = 0;
     std::vector<long> K;                       // K[k] = workgroups in rounds 0..k
@@ -726,7 +725,7 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
       K.push_back(tot);
       if (tot >= nb) { ++ncls; break; }
     }
-    const double a_ = c->wave_cskew / 1000.0, mid = (ncls - 1) / 2.0;
+    const double a_ = cskew / 1000.0, mid = (ncls - 1) / 2.0;
     std::vector<double> wgt((size_t)S);
     double total = 0;
     for (int sp = 0; sp < npairs; ++sp) {
@@ -737,18 +736,37 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
       for (int t = 0; t < spw && spw * sp + t < S; ++t) { wgt[spw * sp + t] = wv; total += wv; }
     }
     double cum = 0;
-    for (int k = 0; k < S; ++k) { b[k] = (int)((double)c->h * (cum / total) + 0.5); cum += wgt[k]; }
+    for (int k = 0; k < S; ++k) { b[k] = (int)((double)h * (cum / total) + 0.5); cum += wgt[k]; }
     for (int k = 1; k < S; ++k) if (b[k] < b[k - 1]) b[k] = b[k - 1];
   } else {
-    const double alpha = c->wave_skew / 1000.0;
+    const double alpha = skew / 1000.0;
     for (int k = 0; k <= S; ++k) {
       long v;
-      if (c->wave_skew == 0) v = (long)k * g.strip_rows;
-      else { const double x = (double)k / S; v = (long)((double)c->h * (x + alpha * x * (1.0 - x))); }
-      b[k] = (int)(v < c->h ? v : c->h);
+      if (skew == 0) v = (long)k * strip_rows;
+      else { const double x = (double)k / S; v = (long)((double)h * (x + alpha * x * (1.0 - x))); }
+      b[k] = (int)(v < h ? v : h);
     }
   }
-  b[S] = c->h;
+  b[S] = h;
+}
+
+// Diagnostic (not part of include/chanvese_hip.h): the strip table for a geometry, without a device.  out needs S + 1 ints.
+extern "C" int cvh_debug_strip_bounds(int kind, int h, int tiles_x, int S, int strip_rows, int nblocks, int cls, int cskew, int skew, int *out)
+{
+  if (!out || S < 1 || h < 1 || (kind != 2 && kind != 3)) return CVH_ERR_ARG;
+  std::vector<int> b;
+  compute_strip_bounds(kind, h, tiles_x, S, strip_rows, nblocks, cls, cskew, skew, b);
+  memcpy(out, b.data(), b.size() * sizeof(int));
+  return CVH_OK;
+}
+
+static int upload_strip_bounds(cvh_context *c, const Geometry &g)
+{
+  const int cls = (((g.strip == 3 && c->wave_cls) || (g.strip == 2 && c->wave_cls == 2)) && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
+  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip, c->h};
+  if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
+  std::vector<int> b;
+  compute_strip_bounds(g.strip, c->h, g.tiles_x, g.tiles_y, g.strip_rows, g.nblocks, cls, c->wave_cskew, c->wave_skew, b);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
   HIPCHK(c, hipMemcpy(c->d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
   memcpy(c->bounds_key, key, sizeof(key));
