@@ -1226,15 +1226,30 @@ extern "C" int cvh_ppf_apply(double *data, int w, long start, long end, int op, 
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: hipSetDevice: %s (no CPU fallback)", hipGetErrorString(e));
   const size_t n = (size_t)(end - start);
+  // OpenCV's backend calls the operator once per sub-range from several host threads: the staging buffer comes from the
+  // device's stream-ordered memory pool (cached between calls; no device-wide synchronisation as with hipMalloc / hipFree)
+  // and everything runs on a stream of its own, so concurrent sub-ranges do not serialise on the null stream.
+  hipStream_t st = nullptr;
+  if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess)
+    return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: hipStreamCreate: %s", hipGetErrorString(e));
   double *d = nullptr;
-  if ((e = hipMalloc((void **)&d, n * sizeof(double))) != hipSuccess)
-    return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: hipMalloc: %s", hipGetErrorString(e));
+  bool pooled = true;
+  if (hipMallocAsync((void **)&d, n * sizeof(double), st) != hipSuccess) {
+    (void)hipGetLastError();
+    pooled = false;
+    if ((e = hipMalloc((void **)&d, n * sizeof(double))) != hipSuccess) {
+      (void)hipStreamDestroy(st);
+      return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: hipMalloc: %s", hipGetErrorString(e));
+    }
+  }
   do {
-    if ((e = hipMemcpy(d, data + start, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
-    if ((e = cvh_launch_ppf(d, n, op, eps, nullptr)) != hipSuccess) break;
-    e = hipMemcpy(data + start, d, n * sizeof(double), hipMemcpyDeviceToHost);
+    if ((e = hipMemcpyAsync(d, data + start, n * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = cvh_launch_ppf(d, n, op, eps, st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(data + start, d, n * sizeof(double), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    e = hipStreamSynchronize(st);
   } while (0);
-  (void)hipFree(d);
+  if (pooled) { (void)hipFreeAsync(d, st); (void)hipStreamSynchronize(st); } else (void)hipFree(d);
+  (void)hipStreamDestroy(st);
   if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: %s", hipGetErrorString(e));
   return CVH_OK;
 }
