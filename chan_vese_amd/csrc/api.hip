@@ -766,7 +766,11 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
   const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip, c->h};
   if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
   std::vector<int> b;
-  compute_strip_bounds(g.strip, c->h, g.tiles_x, g.tiles_y, g.strip_rows, g.nblocks, cls, c->wave_cskew, c->wave_skew, b);
+  // The skew pays for short strips only (one process, 2-pixel kernel: 4096^2, 46 rows: 61.1 -> 58.7 us; 6144^2, 102 rows: 140.9 ->
+  // 140.6; 8192^2 forced onto this kernel, 178 rows: 244 -> 285 us): full below 46 rows, fading to none at 128.
+  int cskew = c->wave_cskew;
+  if (g.strip_rows > 46) cskew = g.strip_rows >= 128 ? 0 : (int)(cskew * (128.0 - g.strip_rows) / (128.0 - 46.0));
+  compute_strip_bounds(g.strip, c->h, g.tiles_x, g.tiles_y, g.strip_rows, g.nblocks, cls, cskew, c->wave_skew, b);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
   HIPCHK(c, hipMemcpy(c->d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
   memcpy(c->bounds_key, key, sizeof(key));
