@@ -60,6 +60,7 @@ struct cvh_context {
   int *d_bounds = nullptr;      // wave kernel: first row of every strip, [tiles_y + 1]
   int bounds_key[4] = {-1, -1, -1, -1};
   int *h_status = nullptr;  // pinned + mapped: {steps_done, stopped} written by the device
+  unsigned long long *d_isums = nullptr, *h_isums = nullptr;   // image_sums_kernel: {sum p, sum p^2} per plane (device / pinned)
   int strip_rows = 0;   // 0 auto
   int num_cus = 256;
   double *d_atan = nullptr;
@@ -156,6 +157,8 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_chain) (void)hipFree(c->d_chain);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->h_status) (void)hipHostFree(c->h_status);
+  if (c->d_isums) (void)hipFree(c->d_isums);
+  if (c->h_isums) (void)hipHostFree(c->h_isums);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 4; ++k) if (c->evp[k]) (void)hipEventDestroy(c->evp[k]);
@@ -172,8 +175,6 @@ static int create_impl(cvh_context *c)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->num_cus = cus;
   }
   for (int k = 0; k < c->C; ++k) HIPCHK(c, hipMalloc((void **)&c->d_img[k], c->n));
-  // 64 doubles of slack behind each level-set buffer: the wave kernel parks the stores of lanes
-  // that own no pixel there (see csv_wave_kernel.hip)
   {
     // one slab for the ping-pong pair (64 doubles of slack behind each buffer: the wave kernels park the stores of lanes
     // that own no pixel there).  Skewing the second buffer against the first by 256 B .. 1 MiB was measured: no effect.
@@ -214,6 +215,8 @@ static int create_impl(cvh_context *c)
   HIPCHK(c, hipMemset(c->d_chain, 0, sizeof(CvhChainAcc)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_status, 64, hipHostMallocMapped));
   c->h_status[0] = 0; c->h_status[1] = 0;
+  HIPCHK(c, hipMalloc((void **)&c->d_isums, 8 * sizeof(unsigned long long)));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_isums, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->evp[k], hipEventDisableTiming));
@@ -356,30 +359,53 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   return CVH_OK;
 }
 
-// tol-free part of the stop condition, src/main.cpp:950-959 (zero-initialised accumulator,
-// channels added serially in k, scaled by 1/C, L2 norm with four squares per step).
-static double stop_norm_host(const std::vector<const uint8_t *> &planes, size_t n, double *sums)
+// tol-free part of the stop condition, src/main.cpp:950-959 (zero-initialised accumulator, channels added serially in k,
+// scaled by 1/C, L2 norm with four squares per step added left to right).  (sum_k I_k)/C squared takes one of 255 C + 1
+// values: the table keeps the reference's rounding and summation order while the loop is integer adds and lookups.
+static double stop_norm_host(const std::vector<const uint8_t *> &planes, size_t n)
 {
   const int C = (int)planes.size();
-  for (int k = 0; k < C; ++k) {
-    unsigned long long t = 0;
-    for (size_t q = 0; q < n; ++q) t += planes[k][q];
-    sums[k] = (double)t;  // exact: < 2^53
-  }
   const double inv = 1.0 / C;
+  double sq[CVH_MAX_CHANNELS * 255 + 1];
+  for (int t = 0; t <= 255 * C; ++t) { const double v = (double)t * inv; sq[t] = v * v; }
+  auto at = [&](size_t q) {
+    int t = 0;
+    for (int k = 0; k < C; ++k) t += planes[k][q];
+    return sq[t];
+  };
   double s = 0;
   size_t i = 0;
-  auto avg = [&](size_t q) {
-    double a = 0;
-    for (int k = 0; k < C; ++k) a += (double)planes[k][q];
-    return a * inv;
-  };
-  for (; i + 4 <= n; i += 4) {
-    const double v0 = avg(i), v1 = avg(i + 1), v2 = avg(i + 2), v3 = avg(i + 3);
-    s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
-  }
-  for (; i < n; ++i) { const double v = avg(i); s += v * v; }
+  for (; i + 4 <= n; i += 4) s += ((at(i) + at(i + 1)) + at(i + 2)) + at(i + 3);
+  for (; i < n; ++i) s += at(i);
   return sqrt(s);
+}
+
+// Sums of the planes resident on the device: sum(I_k) for the region means and, for one channel, the stop norm (exact
+// integers, image_sums_kernel).  Three channels round (sum_k I_k)/3 per pixel, so their norm needs the reference's serial
+// order: `host_planes` (the caller's buffers, or nullptr to fetch the planes) feed stop_norm_host.
+static int image_stats(cvh_context *c, const uint8_t *const *host_planes)
+{
+  HIPCHK(c, hipMemsetAsync(c->d_isums, 0, 8 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, cvh_launch_image_sums(c->d_img, c->C, c->n, c->d_isums, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_isums, c->d_isums, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  const bool exact_on_device = c->C == 1 && c->n < ((size_t)1 << 36);   // 2^36 * 255^2 < 2^53
+  std::vector<std::vector<uint8_t>> fetched;
+  std::vector<const uint8_t *> pl;
+  if (!exact_on_device) {
+    if (host_planes) pl.assign(host_planes, host_planes + c->C);
+    else {
+      try { fetched.assign(c->C, std::vector<uint8_t>(c->n)); } catch (...) { return fail(c, CVH_ERR_NOMEM, "out of host memory"); }
+      for (int k = 0; k < c->C; ++k) {
+        HIPCHK(c, hipMemcpyAsync(fetched[k].data(), c->d_img[k], c->n, hipMemcpyDeviceToHost, c->stream));
+        pl.push_back(fetched[k].data());
+      }
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < c->C; ++k) c->sum_img[k] = (double)c->h_isums[2 * k];   // exact: < 2^53
+  c->stop_norm = exact_on_device ? sqrt((double)c->h_isums[1]) : stop_norm_host(pl, c->n);
+  c->stop_valid = true;
+  return CVH_OK;
 }
 
 extern "C" int cvh_set_image(cvh_context *c, const uint8_t *const *planes)
@@ -387,13 +413,12 @@ extern "C" int cvh_set_image(cvh_context *c, const uint8_t *const *planes)
   if (!c || !planes) return CVH_ERR_ARG;
   for (int k = 0; k < c->C; ++k) if (!planes[k]) return fail(c, CVH_ERR_ARG, "cvh_set_image: plane %d is NULL", k);
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
   for (int k = 0; k < c->C; ++k)
     HIPCHK(c, hipMemcpyAsync(c->d_img[k], planes[k], c->n, hipMemcpyHostToDevice, c->stream));
-  std::vector<const uint8_t *> pl(planes, planes + c->C);
-  c->stop_norm = stop_norm_host(pl, c->n, c->sum_img);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int rc = image_stats(c, planes);
+  if (rc != CVH_OK) return rc;
   c->have_image = true;
-  c->stop_valid = true;
   c->sums_valid = false;
   return CVH_OK;
 }
@@ -469,10 +494,22 @@ extern "C" void cvh_levelset_checkerboard_host(int h, int w, double *u)
 extern "C" int cvh_init_checkerboard(cvh_context *c)
 {
   if (!c) return CVH_ERR_ARG;
-  std::vector<double> u;
-  try { u.resize(c->n); } catch (...) { return fail(c, CVH_ERR_NOMEM, "cvh_init_checkerboard: out of host memory"); }
-  cvh_levelset_checkerboard_host(c->h, c->w, u.data());
-  return cvh_set_levelset(c, u.data());
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the h + w sine factors from the host's libm (as cvh_levelset_checkerboard_host), staged in the idle buffer of the
+  // ping-pong pair (h + w <= h w + 1 doubles); the sign of their product is taken on the device
+  std::vector<double> sv((size_t)c->h + c->w);
+  const double pi = 3.14159265358979323846;
+  for (int i = 0; i < c->h; ++i) sv[i] = sin(pi * i / 5);
+  for (int j = 0; j < c->w; ++j) sv[(size_t)c->h + j] = sin(pi * j / 5);
+  c->cur_base = 0; c->steps_done = 0; c->enqueued = 0;
+  HIPCHK(c, hipMemcpyAsync(c->d_u[1], sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, cvh_launch_checkerboard(c->d_u[1], c->d_u[0], c->h, c->w, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_u = true;
+  c->sums_valid = false;
+  return reset_run_impl(c);
 }
 
 extern "C" int cvh_get_levelset(cvh_context *c, double *u)
@@ -657,17 +694,9 @@ static int prepare_host(cvh_context *c)
 {
   if (!c->have_image) return fail(c, CVH_ERR_STATE, "no image set (call cvh_set_image first)");
   if (!c->have_u) return fail(c, CVH_ERR_STATE, "no level set (call cvh_set_levelset or cvh_init_checkerboard first)");
-  if (!c->stop_valid) {
-    // planes changed on the device (Perona-Malik): src/main.cpp:950 uses the smoothed channels
-    std::vector<std::vector<uint8_t>> host(c->C, std::vector<uint8_t>(c->n));
-    std::vector<const uint8_t *> pl;
-    for (int k = 0; k < c->C; ++k) {
-      HIPCHK(c, hipMemcpyAsync(host[k].data(), c->d_img[k], c->n, hipMemcpyDeviceToHost, c->stream));
-      pl.push_back(host[k].data());
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stop_norm = stop_norm_host(pl, c->n, c->sum_img);
-    c->stop_valid = true;
+  if (!c->stop_valid) {   // planes changed on the device (Perona-Malik): src/main.cpp:950 uses the smoothed channels
+    const int rc = image_stats(c, nullptr);
+    if (rc != CVH_OK) return rc;
   }
   c->stop_cond_h = c->p.tol * c->stop_norm;  // :959 (a launch argument: part of the graph key)
   return CVH_OK;

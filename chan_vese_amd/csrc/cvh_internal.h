@@ -138,6 +138,9 @@ hipError_t cvh_launch_pm_store(const double *state, uint8_t *plane, size_t n, hi
 void cvh_pm_grid(int h, int w, int *tiles_x, int *tiles_y);
 
 hipError_t cvh_launch_contour(const double *u, uint8_t *out, int h, int w, hipStream_t s);
+hipError_t cvh_launch_checkerboard(const double *sv, double *u, int h, int w, hipStream_t s);
+hipError_t cvh_launch_image_sums(const uint8_t *const *planes, int channels, size_t n, unsigned long long *out /* [2 * channels], zeroed */,
+                                 hipStream_t s);
 hipError_t cvh_launch_mask(const double *u, uint8_t *mask, size_t n, int invert, hipStream_t s);
 hipError_t cvh_launch_ppf(double *data, size_t n, int op, double eps, hipStream_t s);
 hipError_t cvh_launch_separate(const uint8_t *img3, const double *u, uint8_t *sel3, size_t n,

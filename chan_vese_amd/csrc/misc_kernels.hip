@@ -47,7 +47,71 @@ __global__ void ppf_kernel(double *data, size_t n, int op, double eps)
   }
 }
 
+// levelset_checkerboard, src/main.cpp:226-231: sign(sin(pi i/5) * sin(pi j/5)).  The two sine vectors come from the host's
+// libm (sv = [h row factors | w column factors]); the product is ONE IEEE multiplication, so the device reproduces
+// cvh_levelset_checkerboard_host bit for bit without 8 bytes per pixel crossing PCIe.
+__global__ void checkerboard_kernel(const double *sv, double *u, int h, int w)
+{
+  for (int i = (int)blockIdx.x; i < h; i += (int)gridDim.x) {
+    const double si = sv[i];
+    for (int j = (int)threadIdx.x; j < w; j += (int)blockDim.x) {
+      const double z = si * sv[h + j];
+      u[(size_t)i * w + j] = (z == 0) ? 0.0 : (z < 0 ? -1.0 : 1.0);
+    }
+  }
+}
+
+// Per-plane sum(p) and sum(p^2) as exact 64-bit integers (out[2k], out[2k+1]; zeroed by the caller): the region means'
+// sum(I) and, for one channel, the tol-free stop norm of src/main.cpp:950-959 (every partial sum of the reference's loop
+// is an integer below 2^53 there, so its result does not depend on the order).
+__global__ void image_sums_kernel(const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, int C, size_t n,
+                                  unsigned long long *out)
+{
+  __shared__ unsigned long long sh[4][6];
+  const uint8_t *pl[3] = {p0, p1, p2};
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+  const size_t pieces = n / 16, stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < C; ++k) {
+    unsigned s1 = 0, s2 = 0;   // flushed every 256 pieces: 256 * 16 * 65025 < 2^32
+    int pending = 0;
+    for (size_t q = t0; q < pieces; q += stride) {
+      const uint4 v = reinterpret_cast<const uint4 *>(pl[k])[q];
+      const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const unsigned x = (wds[i] >> (8 * b)) & 0xffu; s1 += x; s2 += x * x; }
+      }
+      if (++pending == 256) { acc[2 * k] += s1; acc[2 * k + 1] += s2; s1 = s2 = 0; pending = 0; }
+    }
+    for (size_t q = pieces * 16 + t0; q < n; q += stride) { const unsigned x = pl[k][q]; s1 += x; s2 += x * x; }
+    acc[2 * k] += s1; acc[2 * k + 1] += s2;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    unsigned long long v = acc[s];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sh[wave][s] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) atomicAdd(&out[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 }  // namespace
+
+hipError_t cvh_launch_checkerboard(const double *sv, double *u, int h, int w, hipStream_t s)
+{
+  hipLaunchKernelGGL(checkerboard_kernel, dim3(h < 2048 ? h : 2048), dim3(256), 0, s, sv, u, h, w);
+  return hipGetLastError();
+}
+
+hipError_t cvh_launch_image_sums(const uint8_t *const *planes, int channels, size_t n, unsigned long long *out, hipStream_t s)
+{
+  hipLaunchKernelGGL(image_sums_kernel, dim3(flat_grid(n / 16 + 1) > 1024 ? 1024 : flat_grid(n / 16 + 1)), dim3(256), 0, s,
+                     planes[0], channels > 1 ? planes[1] : nullptr, channels > 2 ? planes[2] : nullptr, channels, n, out);
+  return hipGetLastError();
+}
 
 // Contour map of one video frame, src/VideoWriterManager.cpp:60-74: mask = (uint8(round(u)) > 0)
 // (convertTo(CV_8U) rounds half to even and saturates, so mask = rint(u) >= 1), contours by

@@ -109,7 +109,9 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  * chan_vese_amd/csrc/cvh_internal.h.)  Unknown keys and out-of-range values return CVH_ERR_ARG. */
 int cvh_set_option(cvh_context *ctx, const char *key, long value);
 
-/* Uploads the C channel planes (what cv::split produced, src/main.cpp:934-937). */
+/* Uploads the C channel planes (what cv::split produced, src/main.cpp:934-937) and takes their sums on the device
+ * (sum I_k for the region means; the tol-free stop norm of :950-959 — exact integers for one channel, the reference's
+ * serial order on the host for three). */
 int cvh_set_image(cvh_context *ctx, const uint8_t *const *planes);
 /* Downloads the planes (after cvh_perona_malik they hold the smoothed 8-bit image that
  * the reference writes as <stem>_pm, src/main.cpp:943-946). */
@@ -118,9 +120,10 @@ int cvh_get_image(cvh_context *ctx, uint8_t *const *planes);
 /* Level set in / out (src/main.cpp:898-923 produce it, :1004-1005 consume it). */
 int cvh_set_levelset(cvh_context *ctx, const double *u);
 int cvh_get_levelset(cvh_context *ctx, double *u);
-/* levelset_checkerboard, src/main.cpp:221-233.  Evaluated on the HOST in double with
- * libm sin (its sign on every fifth row/column is rounding noise that only the host
- * libm reproduces), then uploaded. */
+/* levelset_checkerboard, src/main.cpp:221-233.  The h + w sine factors are evaluated on the HOST
+ * with libm sin (the sign on every fifth row/column is rounding noise that only the host libm
+ * reproduces) and uploaded; the sign of their product — one IEEE multiplication — is taken on the
+ * device, bit-identical to cvh_levelset_checkerboard_host without 8 bytes per pixel over PCIe. */
 int cvh_init_checkerboard(cvh_context *ctx);
 /* Host-only helper with the same arithmetic, for callers that keep u themselves. */
 void cvh_levelset_checkerboard_host(int h, int w, double *u);

@@ -156,6 +156,43 @@ def test_checkerboard_host_matches_oracle(capi, oracle):
         assert np.array_equal(ctx.get_levelset(), oracle.checkerboard(64, 80))
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (5, 1), (3, 5), (11, 10), (301, 517), (2500, 1200)])
+def test_checkerboard_on_device_is_bit_identical(capi, oracle, shape):
+    """cvh_init_checkerboard uploads h + w sine factors and takes the sign of their product on the device: the level set
+    must be the host function's (and the oracle's) bit for bit, whatever ran on the context before."""
+    h, w = shape
+    with capi.Context(h, w, 1, capi.make_params(tol=0)) as ctx:
+        ctx.init_checkerboard()
+        assert np.array_equal(ctx.get_levelset(), oracle.checkerboard(h, w))
+        ctx.set_image([synth.disk(max(h, w), 200, 50)[:h, :w]])
+        ctx.enqueue_steps(3)          # leaves u in the other buffer, work in flight
+        ctx.init_checkerboard()
+        assert np.array_equal(ctx.get_levelset(), capi.checkerboard_host(h, w))
+        assert ctx.sync()[0] == 0
+
+
+@pytest.mark.parametrize("shape,channels", [((1, 1), 1), ((3, 5), 1), ((7, 9), 3), ((33, 47), 1), ((64, 80), 3), ((1000, 1037), 1), ((500, 777), 3)])
+def test_stop_condition_is_the_oracles_exactly(capi, oracle, shape, channels):
+    """sum(I^2) of one channel is an exact integer sum on the device; three channels keep the reference's serial order on
+    the host: both must equal the oracle's double, not approximate it.  The region means' sum(I_k) ride on the same kernel."""
+    h, w = shape
+    rng = np.random.default_rng(h * 131 + w)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(channels)]
+    with capi.Context(h, w, channels, capi.make_params(tol=0.37)) as ctx:
+        ctx.set_image(planes)
+        ctx.init_checkerboard()
+        assert ctx.get_stop_condition() == oracle.stop_condition(planes, 0.37)
+        planes2 = [255 - p for p in planes]
+        ctx.set_image(planes2)
+        assert ctx.get_stop_condition() == oracle.stop_condition(planes2, 0.37)
+        # c1/c2 use sum(I_k) from the same pass
+        u0 = oracle.checkerboard(h, w)
+        c1, c2 = ctx.get_means()
+        for k in range(channels):
+            assert c1[k] == pytest.approx(oracle.region_mean(planes2[k], u0, 0), rel=1e-12)
+            assert c2[k] == pytest.approx(oracle.region_mean(planes2[k], u0, 1), rel=1e-12)
+
+
 def test_stop_rule_same_iteration(capi, oracle):
     """Default tolerance: the loop must break at the reference's iteration (after the update)."""
     img = synth.disk(128, 200, 50)
@@ -326,7 +363,7 @@ def test_pm_then_csv_pipeline(capi, oracle):
         ctx.set_image([img])
         ctx.perona_malik(30, 0.25, 10)
         ctx.set_levelset(u0)
-        assert ctx.get_stop_condition() == pytest.approx(oracle.stop_condition(sm, 1e-3), rel=1e-14)
+        assert ctx.get_stop_condition() == oracle.stop_condition(sm, 1e-3)   # planes changed on the device: exact all the same
         done_g, _ = ctx.run(60)
         u_g = ctx.get_levelset()
     assert done_g == done_c
