@@ -15,6 +15,9 @@ namespace cvh_dev {
 #ifndef CVH_LOAD_AUX
 #define CVH_LOAD_AUX 0
 #endif
+#ifndef CVH_LOADI_AUX
+#define CVH_LOADI_AUX 0
+#endif
 #ifndef CVH_STORE_AUX
 #define CVH_STORE_AUX 0
 #endif
@@ -43,7 +46,7 @@ __device__ __forceinline__ u32x4_t buf_load_b128(__amdgpu_buffer_rsrc_t r, unsig
   const unsigned v = (voff + soff) * 0x9e3779b1u;
   return u32x4_t{v, v ^ 0x55aa55aau, v + 0x01020304u, v};
 #else
-  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CVH_LOADI_AUX);
 #endif
 }
 __device__ __forceinline__ void buf_store_f64(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)

@@ -15,6 +15,9 @@
 // out-of-image rows / columns were never computed, so it clamps explicitly (own row at the top / bottom edge, own lane at
 // the left / right edge).  Redundant halo rows / columns are computed from the same inputs in the same order by every wave
 // that needs them: identical values, deterministic.
+#ifndef CVH_STORE_AUX
+#define CVH_STORE_AUX 16   // sc1 stores (agent-scope write-through): 2048^2 13.1 -> 12.7 us/step, 4096^2 level (r02 A/B, tools/sessions/r02_aux.sh)
+#endif
 #include "buffer_ops.h"
 #include "csv_device.h"
 
