@@ -1,0 +1,58 @@
+// wave2_device.h — layout constants and 16-byte row accessors shared by the 2-pixel wave kernels
+// (csv_wave2_kernel.hip: one iteration per launch; csv_persist_kernel.hip: a chunk of iterations per launch).
+#pragma once
+#include "csv_device.h"
+#include "buffer_ops.h"
+
+namespace cvh_dev {
+
+constexpr int W2 = 126;      // output columns per wave
+constexpr int XP2 = 130;     // ring slot pitch in doubles (129 used; 1040 bytes keeps 16-byte alignment)
+constexpr int R2 = 4;        // rows per group = ring slots
+constexpr int IMGP2 = 144;   // bytes per row of the per-wave image tile (9 x 16-byte pieces)
+constexpr int NS2 = cvh_nsums(1);
+
+template <bool FAST>
+struct Wave2Smem {
+  static constexpr int wave_doubles = R2 * XP2 + 64 + R2 * IMGP2 / 8;     // ring + scratch + image tile
+  static constexpr int off_x = 0;
+  static constexpr int off_red = off_x + 4 * wave_doubles;                // 4*NS
+  static constexpr int off_fin = off_red + 4 * NS2;                       // NS (+1 pad)
+  static constexpr int off_atan = off_fin + NS2 + 1;                      // FAST: CVH_ATAN2_N
+  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // FAST: 256 x {term, I}
+  static constexpr int off_flag = off_lut + (FAST ? 512 : 0);
+  static constexpr int doubles = off_flag + 2;
+  static constexpr size_t bytes = (size_t)doubles * sizeof(double);
+};
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+// Cache policy of the level-set rows (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1), measured in one process at 4096^2:
+// stores sc1 (agent-scope write-through: no dirty lines pile up in L2) 59.1 -> 58.2 us, plus loads sc0 -> 57.2..57.7 us;
+// nt stores +1.6 us, sc1 loads +0.5 us.
+#ifndef CVH_LOAD2_AUX
+#define CVH_LOAD2_AUX 1
+#endif
+#ifndef CVH_STORE2_AUX
+#define CVH_STORE2_AUX 16
+#endif
+
+// (-DCVH_ABLATE_MEMORY / -DCVH_ABLATE_COMPUTE: diagnostic builds, results wrong by design -- see buffer_ops.h)
+__device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+#ifdef CVH_ABLATE_MEMORY
+  const double v = __builtin_bit_cast(double, 0x4059000000000000ull | (unsigned long long)((voff + soff) & 0xffff));   // ~100: far field
+  return double2_t{v, -v};
+#else
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CVH_LOAD2_AUX));
+#endif
+}
+__device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+#ifndef CVH_ABLATE_MEMORY
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, CVH_STORE2_AUX);
+#else
+  asm volatile("" :: "v"(v.x), "v"(v.y));
+#endif
+}
+
+}  // namespace cvh_dev
