@@ -19,7 +19,9 @@ struct cvh_context {
   size_t n = 0;
   cvh_params p{};
   hipStream_t stream = nullptr;
-  uint8_t *d_img[CVH_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
+  uint8_t *d_img[CVH_MAX_CHANNELS] = {nullptr, nullptr, nullptr};   // planes inside d_img_slab, img_stride bytes apart
+  uint8_t *d_img_slab = nullptr;
+  size_t img_stride = 0;
   double *d_u[2] = {nullptr, nullptr};
   void *d_u_slab = nullptr;
   CvhState *d_state = nullptr;
@@ -141,7 +143,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int k = 0; k < CVH_MAX_CHANNELS; ++k) if (c->d_img[k]) (void)hipFree(c->d_img[k]);
+  if (c->d_img_slab) (void)hipFree(c->d_img_slab);
   if (c->d_u_slab) (void)hipFree(c->d_u_slab);
   for (int k = 0; k < 2; ++k) if (c->d_pm[k]) (void)hipFree(c->d_pm[k]);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -174,7 +176,10 @@ static int create_impl(cvh_context *c)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->num_cus = cus;
   }
-  for (int k = 0; k < c->C; ++k) HIPCHK(c, hipMalloc((void **)&c->d_img[k], c->n));
+  // one slab for the planes: the 1-pixel wave kernel fetches a group's image pieces of all channels with one instruction
+  c->img_stride = (c->n + 255) & ~(size_t)255;
+  HIPCHK(c, hipMalloc((void **)&c->d_img_slab, c->img_stride * c->C));
+  for (int k = 0; k < c->C; ++k) c->d_img[k] = c->d_img_slab + (size_t)k * c->img_stride;
   {
     // one slab for the ping-pong pair (64 doubles of slack behind each buffer: the wave kernels park the stores of lanes
     // that own no pixel there).  Skewing the second buffer against the first by 256 B .. 1 MiB was measured: no effect.
@@ -618,6 +623,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   a->u_in = c->d_u[in_buf];
   a->u_out = c->d_u[in_buf ^ 1];
   for (int k = 0; k < c->C; ++k) a->img[k] = c->d_img[k];
+  a->img_stride = (unsigned)c->img_stride;
   a->st = c->d_state;
   a->partials = c->d_partials;
   a->trace = c->d_trace;

@@ -188,22 +188,27 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     int im[C][R];
     unsigned char *simg = reinterpret_cast<unsigned char *>(xs + R * XPITCH + 64);
     const int icol0 = (WCOLS * wc - 1) & ~15;                      // 16-byte aligned start column (may be < 0)
-    const int ipiece = lane % 5, irow = lane / 5;                  // lanes 0..19: piece of row irow
-    const bool ilane = lane < 5 * R;
+    // lanes 20 ch .. 20 ch + 19: the 5 pieces x 4 rows of channel ch -- the planes live in ONE slab (a.img_stride bytes apart), so a
+    // single load instruction fetches the group's pieces of all channels (3 channels: 60 lanes; 12 -> 10 vector-memory
+    // instructions per group)
+    const int ich = lane / (5 * R), il = lane % (5 * R);
+    const int ipiece = il % 5, irow = il / 5;
+    const bool ilane = lane < 5 * R * C;
     int ipc = icol0 + 16 * ipiece;
     ipc = ipc < 0 ? 0 : (ipc > w - 16 ? w - 16 : ipc);             // clamped pieces only feed clamped columns
     const int ibyte = colc - icol0;                                // this lane's byte within a tile row (0..79)
-    const unsigned voff_i = (unsigned)(ilane ? irow : 0) * (unsigned)w + (unsigned)ipc;
+    const unsigned ich_off = (unsigned)(ilane ? ich : 0) * a.img_stride;
+    const unsigned voff_i = ich_off + (unsigned)(ilane ? irow : 0) * (unsigned)w + (unsigned)ipc;
     // a piece clamped at the image edge lands where its columns are expected
-    unsigned char *ipiece_dst = simg + irow * IMGP + ((icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0);
+    unsigned char *ipiece_dst = simg + (ilane ? ich : 0) * R * IMGP + irow * IMGP + ((icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0);
+    const __amdgpu_buffer_rsrc_t ri_all = make_rsrc(a.img[0], (unsigned)(C - 1) * a.img_stride + (unsigned)h * (unsigned)w);
     // Image samples.  IMGV (w % 16 == 0): the 64-byte row segments of 4 rows are fetched as
     // 20 aligned 16-byte pieces by ONE load (lanes 0..19), staged in a per-wave LDS tile and
     // read back as bytes: one vector-memory instruction per 4 rows instead of one 64 x 1-byte
     // load per row (measured: the byte loads alone cost ~18 us of a 4096^2 launch).
-    auto IMQ = [&](int ch, int r0) -> u32x4_t {
-      const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[ch], (unsigned)h * (unsigned)w);
-      if (r0 + R - 1 <= ilast) return buf_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w);
-      return buf_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, ilast) * (unsigned)w + (unsigned)ipc, 0u);
+    auto IMQ = [&](int r0) -> u32x4_t {
+      if (r0 + R - 1 <= ilast) return buf_load_b128(ri_all, voff_i, (unsigned)r0 * (unsigned)w);
+      return buf_load_b128(ri_all, ich_off + (unsigned)clampi(r0 + (ilane ? irow : 0), 0, ilast) * (unsigned)w + (unsigned)ipc, 0u);
     };
     auto lds_fence = [&]() {
       // the ring is exchanged between LANES of this wave: LDS operations of one wave execute in
@@ -213,16 +218,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // parks the next group's data: rows T[j] -> slot j, extras, image pieces / bytes
-    auto park = [&](const double (&T)[R], double X, const u32x4_t (&IQ)[C], const int (&IB)[C][R]) {
+    auto park = [&](const double (&T)[R], double X, u32x4_t IQ, const int (&IB)[C][R]) {
       lds_fence();                              // all reads of the current group are done
 #pragma unroll
       for (int j = 0; j < R; ++j) x_own[j * XPITCH] = T[j];
       *x_ext = X;
       if (IMGV) {
-        if (ilane) {
-#pragma unroll
-          for (int ch = 0; ch < C; ++ch) *reinterpret_cast<u32x4_t *>(ipiece_dst + ch * R * IMGP) = IQ[ch];
-        }
+        if (ilane) *reinterpret_cast<u32x4_t *>(ipiece_dst) = IQ;
       }
       lds_fence();
 #pragma unroll
@@ -237,16 +239,16 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
     double uw, ue;
     {
       double T[R];
-      u32x4_t IQ[C];
+      u32x4_t IQ = {0, 0, 0, 0};
       int IB[C][R];
 #pragma unroll
       for (int j = 0; j < R; ++j) T[j] = U(s0 + 1 + j);
       const double X0 = UX(s0);                 // extras of rows s0 .. s0+3: only row s0's are used
       const double X = UX(s0 + 1);              // extras of rows s0+1 .. s0+4
+      if (IMGV) IQ = IMQ(s0);
+      else {
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        if (IMGV) IQ[ch] = IMQ(ch, s0);
-        else {
+        for (int ch = 0; ch < C; ++ch) {
 #pragma unroll
           for (int k = 0; k < R; ++k) IB[ch][k] = IM(ch, s0 + k);
         }
@@ -414,15 +416,15 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       }
       // requests for the next group (rows ib+4 .. ib+7; its `up` rows are ib+5 .. ib+8)
       double T[R];
-      u32x4_t IQ[C];
+      u32x4_t IQ = {0, 0, 0, 0};
       int IB[C][R];
 #pragma unroll
       for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
       const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
+      if (IMGV) IQ = INTERIOR ? buf_load_b128(ri_all, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
+      else {
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        if (IMGV) IQ[ch] = INTERIOR ? buf_load_b128(make_rsrc(a.img[ch], (unsigned)h * (unsigned)w), voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ch, ib + R);
-        else {
+        for (int ch = 0; ch < C; ++ch) {
 #pragma unroll
           for (int k = 0; k < R; ++k) IB[ch][k] = IM(ch, ib + R + k);
         }

@@ -49,6 +49,7 @@ struct CvhStepArgs {
   const double *u_in;
   double *u_out;
   const uint8_t *img[CVH_MAX_CHANNELS];
+  unsigned img_stride;           // the planes are img[0] + k * img_stride (one slab)
   CvhState *st;
   double *partials;  // [nblocks][nsums]
   double *trace;     // [trace_cap][2C+1] or null
