@@ -223,11 +223,14 @@ def main():
             launches += 64
         return launches
 
-    prewarm_launches = prewarm()
     run_steps(args.warmup)
     sync_all()
     for ctx in ctxs:
         ctx.warm(steps if len(ctxs) == 1 else 8)   # hipGraph capture/instantiate is one-off host work: not a step
+    # the device warm-up comes LAST, directly before the timed region (the graph build above leaves the GPU idle for a
+    # millisecond or two).  Short runs stay exposed to the box: over five boxes the 20-step line read 57.9-59.6 us on four
+    # and, in some processes of one, 64-73 us with either order of these steps
+    prewarm_launches = prewarm()
     barrier()
     sync_all()
     t0 = time.perf_counter()
@@ -283,7 +286,7 @@ def main():
             "data": "synthetic" if not dry else "dry-run",
             "config": {"workload": workload, "images_per_gpu": images, "images_total": images * world,
                        "state": "fp64", "math": args.math,
-                       "device_prewarm": f"{prewarm_launches} launches on a scratch context before the warm-up steps", "parallelism": f"batch-shard x{world}",
+                       "device_prewarm": f"{prewarm_launches} launches on a scratch context between the warm-up steps and the timed steps", "parallelism": f"batch-shard x{world}",
                        "ranks_in_group": (dist.get_world_size() if dist is not None else 1),
                        "backend": (dist.get_backend() if dist is not None else "none"),
                        "per_rank_mpx_it_s": [r[1] / r[2] / 1e6 for r in records]},
@@ -299,12 +302,13 @@ def main():
     # field of H_eps), 17-100, 101-500; one sync per segment, nothing else in the timed spans
     if world == 1 and not dry and not args.no_phases and images == 1:
         ctx = ctxs[0]
-        ctx.init_checkerboard()          # on the device: no 134 MB upload between the warm-up below and the first segment
-        prewarm()                        # the CPU baseline above left the GPU idle for seconds: same clock state as the timed region
+        ctx.init_checkerboard()          # on the device: no 134 MB upload before the first segment
         phases = {}
         lo = 1
         for seg in (16, 84, 400):
             ctx.warm(seg)
+            if lo == 1:
+                prewarm()                # same clock state as the timed region, no host work between it and the first segment
             ctx.enqueue_steps(seg)
             ctx.sync()
             phases[f"{lo}-{lo + seg - 1}"] = ctx.last_run_ms() * 1e3 / seg
