@@ -34,7 +34,7 @@ struct cvh_context {
   uint8_t *d_mask = nullptr;
   bool have_image = false, have_u = false, sums_valid = false, stop_valid = false;
   double stop_norm = 0.0;  // || (sum_k I_k)/C ||_2
-  double stop_cond_h = 0.0; // staging for the async upload
+  double stop_cond_h = 0.0; // tol * stop_norm of the current run (a launch argument)
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
   int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
@@ -713,7 +713,7 @@ static int prepare(cvh_context *c)
 {
   int rc0 = prepare_host(c);
   if (rc0 != CVH_OK) return rc0;
-  HIPCHK(c, hipMemcpyAsync(&c->d_state->stop_cond, &c->stop_cond_h, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // (the stop condition travels as a launch argument, CvhStepArgs::stop_cond: no per-enqueue upload inside the timed interval)
   const bool chain = use_chain(c, resolve_geometry(c));
   if (chain && !c->chain_acc_valid) c->sums_valid = false;   // the means exist only as doubles (another kernel ran): recompute
   if (!c->sums_valid) {

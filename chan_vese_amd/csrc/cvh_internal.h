@@ -25,7 +25,7 @@ struct CvhState {
   double c1[CVH_MAX_CHANNELS];  // region means of the current u, used by the next step (:973)
   double c2[CVH_MAX_CHANNELS];  // (:974)
   double norm;                  // ||u_diff||_2 of the last executed step (:993)
-  double stop_cond;             // tol * ||mean_k I_k||_2 (:959)
+  double stop_cond;             // (unused: the stop condition is a launch argument, CvhStepArgs::stop_cond)
   int steps_done;               // iterations executed since cvh_reset_run
   int stopped;                  // sticky: stop rule fired (:1000); later launches are no-ops
   unsigned ticket;              // arrival counter of the in-kernel finalisation
