@@ -950,11 +950,17 @@ static int absorb_state(cvh_context *c, const CvhState *hs)
 
 static int sync_impl(cvh_context *c)
 {
+  const bool via_flush = c->chain_pending;   // the flush kernel writes {steps_done, stopped, norm} into the pinned host block itself
   int rc = chain_flush(c);
   if (rc != CVH_OK) return rc;
   if (c->timing_open) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+  if (!via_flush) HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (via_flush) {
+    c->h_state[0].steps_done = c->h_status[0];
+    c->h_state[0].stopped = c->h_status[1];
+    memcpy(&c->h_state[0].norm, &c->h_status[2], sizeof(double));
+  }
   if (c->timing_open) {
     HIPCHK(c, hipEventElapsedTime(&c->last_run_ms, c->ev0, c->ev1));
     c->timing_open = false;

@@ -20,6 +20,14 @@ __global__ __launch_bounds__(CVH_BLOCK) void csv_chain_flush_kernel(const CvhSte
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < C; ++k) { a.st->c1[k] = c1[k]; a.st->c2[k] = c2[k]; }
+    // what cvh_sync reports, straight into the pinned host block {steps_done, stopped, norm}: no device-to-host copy behind the flush
+    if (a.host_status) {
+      const long long nb = __double_as_longlong(a.st->norm);
+      __hip_atomic_store(&a.host_status[2], (int)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.host_status[3], (int)(nb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.host_status[1], a.st->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.host_status[0], a.st->steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
