@@ -538,10 +538,12 @@ static Geometry resolve_geometry(const cvh_context *c)
   // default: the wave kernel (any width; fastest measured); it addresses the level set through
   // buffer instructions with 32-bit byte offsets and marks dropped lanes with offset 2^31, so
   // images of 2^28 pixels (2 GiB of level set) or more use the tile kernel
-  // auto: the 2-pixel kernel up to ~6144^2 (measured ahead of the 1-pixel kernel at 512^2 .. 5120^2, level at 6144^2,
+  // auto: the 2-pixel kernel up to 24 Mpixel (end of round 2, one process each: 4096^2 59.6 vs 64.3 us, 4608^2 85.3 vs 87.6, 5120^2 98.2 vs
+  // 96.8, 6144^2 144.6 vs 140.3, 4320x7680 129.7 vs 123.0: from ~5120^2 on the 1-pixel kernel's 5 waves/SIMD win).  Earlier reading:
+  // (measured ahead of the 1-pixel kernel at 512^2 .. 5120^2, level at 6144^2,
   // 4 % behind at 8192^2, tools/size_sweep.sh)
   // (auto: below ~0.6 Mpixel the 1-pixel kernel's twice-as-many waves win: 512^2 8.2 vs 9.1 us; 1024^2 12.9 vs 11.9 us)
-  if ((c->kernel == 3 || (c->kernel == -1 && c->n <= (size_t)40000000 && c->n >= (size_t)600000)) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 &&
+  if ((c->kernel == 3 || (c->kernel == -1 && c->n <= (size_t)24000000 && c->n >= (size_t)600000)) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 &&
       c->n < ((size_t)1 << 28)) {
     // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
     // one round of resident waves (3 or 4 per SIMD)
