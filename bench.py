@@ -268,7 +268,7 @@ def main():
             except Exception:
                 traffic = None
         kopt = dict(kv.split("=") for kv in (args.opt or [])).get("kernel", "-1")
-        two_px = C == 1 and n % 16 == 0 and n >= 144 and (kopt == "3" or (kopt == "-1" and n * n <= 24000000))   # api.hip resolve_geometry
+        two_px = C == 1 and n % 16 == 0 and n >= 144 and (kopt == "3" or (kopt == "-1" and n * n >= 600000))   # api.hip resolve_geometry
         kernel_name = {"0": "csv_step_kernel (tile)", "1": "csv_strip_kernel"}.get(kopt, "csv_wave2_kernel" if two_px else "csv_wave_kernel")
         workload = f"{name}: {n}x{n} {C}-channel {desc}, checkerboard init, {steps} CSV iterations after {args.warmup} warm-up, tol 0"
         out = {

@@ -56,6 +56,7 @@ struct cvh_context {
   bool chain_pending = false;   // chain launches enqueued since the last flush
   bool chain_acc_valid = false; // the fixed-point sets hold the sums of the current level set
   int far_terms = 5;            // terms of the far-field series of H_eps (5: valid from 32 eps, 4: from 64 eps)
+  int wave_pol = -1;            // option "wave_pol": cache policy of the 2-pixel kernel's rows (-1 auto by footprint, 0 plain, 1 write-through)
   int wave_cls = 1;             // 2-pixel wave kernel: class-major workgroup numbering (dispatch rounds)
   int wave_cskew = 500;         // per-mille strip-length skew between dispatch rounds (see upload_strip_bounds); measured
                                 // in one process at 4096^2: 0 -> 61.1, 300 -> 59.3, 500 -> 58.7, 750 -> 58.5, 900 -> 59.2 us
@@ -319,6 +320,9 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "far_terms")) {
     if (value != 4 && value != 5) return fail(c, CVH_ERR_ARG, "far_terms must be 4 or 5");
     c->far_terms = (int)value;
+  } else if (!strcmp(key, "wave_pol")) {
+    if (value < -1 || value > 1) return fail(c, CVH_ERR_ARG, "wave_pol must be -1 (auto), 0 or 1");
+    c->wave_pol = (int)value;
   } else if (!strcmp(key, "wave_cls")) {
     if (value < 0 || value > 2) return fail(c, CVH_ERR_ARG, "wave_cls must be 0 (off), 1 (2-pixel kernel) or 2 (1-pixel kernel too)");
     c->wave_cls = (int)value;
@@ -538,12 +542,10 @@ static Geometry resolve_geometry(const cvh_context *c)
   // default: the wave kernel (any width; fastest measured); it addresses the level set through
   // buffer instructions with 32-bit byte offsets and marks dropped lanes with offset 2^31, so
   // images of 2^28 pixels (2 GiB of level set) or more use the tile kernel
-  // auto: the 2-pixel kernel up to 24 Mpixel (end of round 2, one process each: 4096^2 59.6 vs 64.3 us, 4608^2 85.3 vs 87.6, 5120^2 98.2 vs
-  // 96.8, 6144^2 144.6 vs 140.3, 4320x7680 129.7 vs 123.0: from ~5120^2 on the 1-pixel kernel's 5 waves/SIMD win).  Earlier reading:
-  // (measured ahead of the 1-pixel kernel at 512^2 .. 5120^2, level at 6144^2,
-  // 4 % behind at 8192^2, tools/size_sweep.sh)
-  // (auto: below ~0.6 Mpixel the 1-pixel kernel's twice-as-many waves win: 512^2 8.2 vs 9.1 us; 1024^2 12.9 vs 11.9 us)
-  if ((c->kernel == 3 || (c->kernel == -1 && c->n <= (size_t)24000000 && c->n >= (size_t)600000)) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 &&
+  // auto: the 2-pixel kernel from 0.6 Mpixel up (end of round 2, one context per size, 2-pixel with its cache policy chosen by
+  // footprint vs 1-pixel: 3000x4000 40.3 vs 43.8 us, 4096^2 59.4 vs 64.7, 4608^2 80.5 vs 87.2, 5120^2 93.1 vs 97.2, 6144^2 133.0 vs
+  // 140.7, 4320x7680 122.7 vs 123.2, 8192^2 243.3 vs 245.5)
+  if ((c->kernel == 3 || (c->kernel == -1 && c->n >= (size_t)600000)) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 &&
       c->n < ((size_t)1 << 28)) {
     // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
     // one round of resident waves (3 or 4 per SIMD)
@@ -673,6 +675,8 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   // class-major numbering + class skew: the 2-pixel kernel by default (measured there: -2.3 us at 4096^2); the 1-pixel kernel only
   // on request ("wave_cls" = 2): measured neutral to slightly worse there (4096^2 x 3 channels: 77.2 plain, 77.3 class-major, 82.5 with
   // skew 500; 1 channel: 63.6 / 64.3)
+  // write-through stores pay while the ping-pong pair and the planes (mostly) fit the 256 MiB Infinity Cache: up to ~300 MB of footprint
+  a->wave_pol = c->wave_pol >= 0 ? c->wave_pol : ((double)c->n * (16.0 + c->C) <= 300e6 ? 1 : 0);
   a->wave_cls = (((g.strip == 3 && c->wave_cls) || (g.strip == 2 && c->wave_cls == 2)) && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
   a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
@@ -1140,6 +1144,7 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   memset(&a, 0, sizeof(a));
   a.h = c->h; a.w = c->w; a.K2 = K * K; a.L = L;
   a.invK2 = 1.0 / (K * K); a.L4 = L / 4; a.fast = use_fast(c) ? 1 : 0;
+  a.pol = (c->wave_pol >= 0 ? c->wave_pol : ((double)c->n * 16.0 <= 300e6 ? 1 : 0));
   // auto: the 2-pixel kernel for large planes (measured 50.4 vs 53.3 us/step at 4096^2, but 19 vs 15.7 at 2048^2:
   // its strips get too short there), the 1-pixel wave kernel otherwise
   const bool pm2_ok = c->w % 2 == 0 && c->w >= 128 && c->n < ((size_t)1 << 28);

@@ -23,7 +23,7 @@ using namespace cvh_dev;
 
 namespace {
 
-template <bool FAST, int MINW>
+template <bool FAST, int MINW, int POL>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhStepArgs a)
 {
   using L = Wave2Smem<FAST>;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     const unsigned voff_x = ((unsigned)xrow * (unsigned)w + (unsigned)xcol) * 8u;
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u_in, ubytes);
     const int ulast = s1 < h - 1 ? s1 : h - 1, ilast = s1 - 1;
-    auto U = [&](int r) -> double2_t { return buf_load_f64x2(ru, voff_u, (unsigned)clampi(r, 0, ulast) * rowbytes); };
+    auto U = [&](int r) -> double2_t { return buf_load_f64x2<POL>(ru, voff_u, (unsigned)clampi(r, 0, ulast) * rowbytes); };
     auto UX = [&](int r0) -> double {
       if (r0 + R - 1 <= ulast) return buf_load_f64(ru, voff_x, (unsigned)r0 * rowbytes);
       return buf_load_f64(ru, ((unsigned)clampi(r0 + xrow, 0, ulast) * (unsigned)w + (unsigned)xcol) * 8u, 0u);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       {   // keeps every load, LDS exchange and the store; no arithmetic
         keep[k] = double2_t{u0.x + (up.x + um.x + uw) * 1e-30 + (double)ba * 1e-30, u0.y + (up.y + um.y + ue) * 1e-30 + (double)bb * 1e-30};
         near_mask[k] = 0ull;
-        buf_store_f64x2(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+        buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
         acc[0] += keep[k].x; acc[4] += 1.0;   // a non-zero norm: the stop rule must not fire
         um = u0; u0 = up; uw = uw_n; ue = ue_n;
         return;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       } else {
         hva = heaviside_strict(va, eps); hvb = heaviside_strict(vb, eps);
       }
-      buf_store_f64x2(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+      buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {
         if (FAST) {
           acc[0] += hva; acc[0] += hvb;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       }
       double2_t T[R];
 #pragma unroll
-      for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64x2(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
+      for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64x2<POL>(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
       const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
       const u32x4_t IQ = INTERIOR ? buf_load_b128(ri, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
 #pragma unroll
@@ -379,13 +379,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   if (a.dbg_times && tid == 0) a.dbg_times[(size_t)a.nparts * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <bool FAST, int MINW>
+template <bool FAST, int MINW, int POL>
 hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 {
   using L = Wave2Smem<FAST>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup
-  hipLaunchKernelGGL((csv_wave2_kernel<FAST, MINW>), dim3(a.nparts + extra), dim3(CVH_BLOCK), L::bytes, s, a);
+  hipLaunchKernelGGL((csv_wave2_kernel<FAST, MINW, POL>), dim3(a.nparts + extra), dim3(CVH_BLOCK), L::bytes, s, a);
   return hipGetLastError();
 }
 
@@ -395,7 +395,8 @@ int cvh_wave2_cols() { return W2; }
 
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s)
 {
-  if (!fast) return launch_wave2<false, 2>(a, s);
+  if (!fast) return launch_wave2<false, 2, 1>(a, s);
   // default: 3 waves/SIMD with branch-free rows (measured 65.1 vs 66.3 us for 4 waves/SIMD with the per-row branch)
-  return a.wave_minw == 4 ? launch_wave2<true, 4>(a, s) : launch_wave2<true, 3>(a, s);
+  if (a.wave_minw == 4) return launch_wave2<true, 4, 1>(a, s);
+  return a.wave_pol ? launch_wave2<true, 3, 1>(a, s) : launch_wave2<true, 3, 0>(a, s);   // cache policy of the rows: wave2_device.h
 }

@@ -92,6 +92,7 @@ struct CvhStepArgs {
   int chain_pb;                  // set that held the sums of u when the run counter was last reset (flush: set = pb + steps_done)
   double chain_scale[4], chain_inv[4];   // powers of two: fixed-point scale of sum (H-1/2), sum I_k (H-1/2) and their inverses
   double *chain_s4;              // [2][nparts] per-workgroup sum u_diff^2 rows, by launch parity
+  int wave_pol;                  // 2-pixel wave kernel: cache policy of the level-set rows (wave2_device.h): 1 write-through stores, 0 plain
   int wave_cls;                  // 2-pixel wave kernel: workgroups per XCD per dispatch round (= CUs per XCD); > 0 numbers the
                                  // workgroups class-major (round 0 of every XCD first), 0 = plain XCD-contiguous numbering
 };
@@ -109,6 +110,7 @@ struct CvhPmArgs {
   double invK2, L4;  // FAST flavour: 1/K^2, L/4
   int fast;
   int strip_rows;    // wave kernel: rows per wave
+  int pol;           // 2-step wave kernel: 1 = write-through stores (the state planes fit the Infinity Cache), 0 = plain
 };
 
 // ---- launchers (csv_kernels.hip / pm_kernels.hip / misc_kernels.hip) ----

@@ -15,9 +15,6 @@
 // out-of-image rows / columns were never computed, so it clamps explicitly (own row at the top / bottom edge, own lane at
 // the left / right edge).  Redundant halo rows / columns are computed from the same inputs in the same order by every wave
 // that needs them: identical values, deterministic.
-#ifndef CVH_STORE_AUX
-#define CVH_STORE_AUX 16   // sc1 stores (agent-scope write-through): 2048^2 13.1 -> 12.7 us/step, 4096^2 level (r02 A/B, tools/sessions/r02_aux.sh)
-#endif
 #include "buffer_ops.h"
 #include "csv_device.h"
 
@@ -34,7 +31,9 @@ struct PmStage {
   double gw, ge;          // g(i, col -/+ 1) of the row being produced
 };
 
-template <bool FAST>
+// POL 1: stores carry sc1 (agent-scope write-through) -- 2048^2 13.1 -> 12.7 us/step while the two state planes live in the Infinity
+// Cache; plain stores (POL 0) beyond it, where write-through costs (CvhPmArgs::pol, chosen by footprint in api.hip; cf. wave2_device.h)
+template <bool FAST, int POL>
 __global__ __launch_bounds__(CVH_BLOCK, 4) void pm_wave_k2_kernel(const CvhPmArgs a)
 {
   __shared__ double sx[4][16 * 64];   // per wave: stage 1 {4 rows of I, 4 rows of g}, stage 2 {4, 4}
@@ -180,7 +179,8 @@ __global__ __launch_bounds__(CVH_BLOCK, 4) void pm_wave_k2_kernel(const CvhPmArg
       const double v2 = stage_finish(B, sI2, sG2, lw2, le2, k2, i2, true, g2);
       // lanes without an output column are dropped by the hardware (offset beyond the buffer), rows past the strip
       // end by an empty resource
-      buf_store_f64(v2, i2 < s1 ? rout : make_rsrc(a.out, 0u), voff_st, (unsigned)i2 * rowbytes);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v2), i2 < s1 ? rout : make_rsrc(a.out, 0u), voff_st, (unsigned)i2 * rowbytes,
+                                            POL ? 16 : 0);
     }
   }
 }
@@ -192,7 +192,9 @@ int cvh_pm_wave_k2_cols() { return P2C; }
 hipError_t cvh_launch_pm_wave_k2(const CvhPmArgs &a, hipStream_t s)
 {
   const int nbc = (a.tiles_x + 3) / 4, nstr = (a.h + a.strip_rows - 1) / a.strip_rows;
-  if (a.fast) hipLaunchKernelGGL(pm_wave_k2_kernel<true>, dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
-  else hipLaunchKernelGGL(pm_wave_k2_kernel<false>, dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  if (a.fast && a.pol) hipLaunchKernelGGL((pm_wave_k2_kernel<true, 1>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  else if (a.fast) hipLaunchKernelGGL((pm_wave_k2_kernel<true, 0>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  else if (a.pol) hipLaunchKernelGGL((pm_wave_k2_kernel<false, 1>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  else hipLaunchKernelGGL((pm_wave_k2_kernel<false, 0>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
   return hipGetLastError();
 }

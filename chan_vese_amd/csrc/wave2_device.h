@@ -26,30 +26,26 @@ struct Wave2Smem {
 };
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
-// Cache policy of the level-set rows (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1), measured in one process at 4096^2:
-// stores sc1 (agent-scope write-through: no dirty lines pile up in L2) 59.1 -> 58.2 us, plus loads sc0 -> 57.2..57.7 us;
-// nt stores +1.6 us, sc1 loads +0.5 us.
-#ifndef CVH_LOAD2_AUX
-#define CVH_LOAD2_AUX 1
-#endif
-#ifndef CVH_STORE2_AUX
-#define CVH_STORE2_AUX 16
-#endif
-
+// Cache policy of the level-set rows (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1).  POL 1: stores sc1 (agent-scope write-through: no
+// dirty lines pile up in the XCD's L2) and loads sc0 -- faster while the ping-pong pair (mostly) fits the 256 MiB Infinity Cache
+// (2048^2: 20.9 vs 22.1 us; 4096^2: 0..-1.3 us); POL 0: plain -- faster beyond it (4608^2: 80.6 vs 85.2 us; 5120^2: 100.5 vs 110.2 us).
+// The host picks by footprint (api.hip, fill_args); nt stores +1.6 us, sc1 loads +0.5 us at 4096^2.
 // (-DCVH_ABLATE_MEMORY / -DCVH_ABLATE_COMPUTE: diagnostic builds, results wrong by design -- see buffer_ops.h)
+template <int POL>
 __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
 #ifdef CVH_ABLATE_MEMORY
   const double v = __builtin_bit_cast(double, 0x4059000000000000ull | (unsigned long long)((voff + soff) & 0xffff));   // ~100: far field
   return double2_t{v, -v};
 #else
-  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CVH_LOAD2_AUX));
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL ? 1 : 0));
 #endif
 }
+template <int POL>
 __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
 #ifndef CVH_ABLATE_MEMORY
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, CVH_STORE2_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL ? 16 : 0);
 #else
   asm volatile("" :: "v"(v.x), "v"(v.y));
 #endif

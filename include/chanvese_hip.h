@@ -94,7 +94,7 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "trace"          capacity (iterations) of the per-iteration trace, 0 = off
  *   "sync_every"     iterations enqueued between host polls of the stop flag (default 32)
  *   "graph"          1 = runs of 16 steps are replayed as one hipGraph (default), 0 = plain launches
- *   "kernel"         data flow of the CSV step: -1 auto (3 where it applies -- 1 channel, width a multiple of 16 and >= 144, 0.6 .. 24 Mpixel --
+ *   "kernel"         data flow of the CSV step: -1 auto (3 where it applies -- 1 channel, width a multiple of 16 and >= 144, from 0.6 Mpixel --
  *                    else 2; 0 from 2^28 pixels),
  *                    0 LDS tile, 1 streaming strip (w % 16 == 0), 2 wave-streaming, 3 wave-streaming with
  *                    2 pixels per lane (1 channel, w % 16 == 0, w >= 144; other shapes fall back to 2)

@@ -1,6 +1,6 @@
 """A/B of two (or more) BUILDS of libchanvese_hip.so inside ONE process: each library gets its own context on the same image,
 the contexts take turns (STEPS iterations each, REPS rounds); prints HIP-event us per iteration per library and round.
-usage: ab_libs.py path/to/libA.so path/to/libB.so ...   [N=4096 REPS=4 STEPS=112]"""
+usage: ab_libs.py path/to/libA.so path/to/libB.so ...   [N=4096 REPS=4 STEPS=112 OPTS=key=value,...]"""
 import ctypes as C, os, sys
 sys.path.insert(0, '.')
 import numpy as np
@@ -13,6 +13,8 @@ for path in sys.argv[1:]:
     L = capi.lib()
     if u0 is None: u0 = capi.checkerboard_host(n, n)
     ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
+    for kv in os.environ.get("OPTS", "").split(","):     # e.g. OPTS=kernel=3,wave_cskew=400
+        if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ctx.set_image([img]); ctx.set_levelset(u0); ctx.enqueue_steps(400); ctx.sync()
     ctxs.append((path, ctx))
 res = np.zeros((len(ctxs), reps))

@@ -10,7 +10,7 @@ for rep in range(2):
     for arg in sys.argv[1:]:
         opts = dict((k, int(v)) for k, v in (kv.split("=") for kv in arg.split(",")))
         ctx.set_option("pm_kernel", opts.get("pm_kernel", -1)); ctx.set_option("pm_strip_rows", opts.get("pm_strip_rows", 0))
-        ctx.set_option("graph", opts.get("graph", 1))
+        ctx.set_option("graph", opts.get("graph", 1)); ctx.set_option("wave_pol", opts.get("wave_pol", -1))
         ctx.set_image(img); ctx.perona_malik(30, 0.25, 250)
         ms = ctx.last_pm_ms()
         print("%-40s %.2f us/step  frac %.3f" % (arg, ms, 16.0 * n * n / (ms * 1e-6) / 8e12), flush=True)
