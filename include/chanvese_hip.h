@@ -98,6 +98,9 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *                    else 2; 0 from 2^28 pixels),
  *                    0 LDS tile, 1 streaming strip (w % 16 == 0), 2 wave-streaming, 3 wave-streaming with
  *                    2 pixels per lane (1 channel, w % 16 == 0, w >= 144; other shapes fall back to 2)
+ *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while ONE context's ping-pong
+ *                    pair fits the Infinity Cache, <= 300 MB), 0 plain, 1 write-through; a caller that keeps several
+ *                    contexts busy on one GPU should set 0
  *   "tile_rows"      tile/strip kernels: rows per tile (0 auto, 12/14/16)
  *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
  *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
