@@ -52,7 +52,9 @@ struct WaveSmem {
 #define CVH_STORE_MOD ""
 #endif
 
-template <int C, bool FAST, bool LUT, int MINW, bool IMGV, int G>
+// POL: cache policy of the level-set stores (1 = sc1 write-through while the pair fits the Infinity Cache: 1000^2 12.4 -> 11.65 us; beyond
+// it write-through costs -- 6144^2: 144 -> 171 us; wave2_device.h has the 2-pixel kernel's figures), chosen by the host (wave_pol)
+template <int C, bool FAST, bool LUT, int MINW, bool IMGV, int G, int POL = 0>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStepArgs a)
 {
   using L = WaveSmem<C, FAST, LUT, G>;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
 #ifdef CVH_ABLATE_COMPUTE
       if (FAST) {
         const double un_ = u0 + (up + um + uw + ue) * 1e-30 + (double)im[0][k] * 1e-30;
-        buf_store_f64(un_, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, un_), make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes, POL ? 16 : 0);
         acc[0] += un_;
         um = u0; u0 = up; uw = uw_n; ue = ue_n;
         return;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       }
       else hv = heaviside_strict(un, eps);
       // rows past the strip end (wave-uniform) get an empty buffer: every lane is out of range
-      buf_store_f64(un, make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, un), make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes, POL ? 16 : 0);
       if (live) {  // halo / out-of-image lanes are zeroed once after the loop
         acc[0] += hv;
         if (!FAST) acc[1] += (1 - hv);
@@ -498,6 +500,13 @@ hipError_t launch_wave_g(const CvhStepArgs &a, hipStream_t s)
   }
   const bool imgv = a.w % 16 == 0 && a.w >= 80 && a.wave_imgv;
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup of chain mode
+  if constexpr (FAST && LUT && G == 1) {   // the shipped flavours exist with write-through stores too
+    if (a.wave_pol) {
+      if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G, 1>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
+      else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G, 1>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
+      return hipGetLastError();
+    }
+  }
   if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
   else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
   return hipGetLastError();
