@@ -31,6 +31,12 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // (2048^2: 20.9 vs 22.1 us; 4096^2: 0..-1.3 us); POL 0: plain -- faster beyond it (4608^2: 80.6 vs 85.2 us; 5120^2: 100.5 vs 110.2 us).
 // The host picks by footprint (api.hip, fill_args); nt stores +1.6 us, sc1 loads +0.5 us at 4096^2.
 // (-DCVH_ABLATE_MEMORY / -DCVH_ABLATE_COMPUTE: diagnostic builds, results wrong by design -- see buffer_ops.h)
+#ifndef CVH_POL0_LOAD_AUX
+#define CVH_POL0_LOAD_AUX 0    // A/B builds (tools/build_variant.sh)
+#endif
+#ifndef CVH_POL0_STORE_AUX
+#define CVH_POL0_STORE_AUX 0
+#endif
 template <int POL>
 __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
@@ -38,14 +44,14 @@ __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, un
   const double v = __builtin_bit_cast(double, 0x4059000000000000ull | (unsigned long long)((voff + soff) & 0xffff));   // ~100: far field
   return double2_t{v, -v};
 #else
-  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL ? 1 : 0));
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL ? 1 : CVH_POL0_LOAD_AUX));
 #endif
 }
 template <int POL>
 __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
 #ifndef CVH_ABLATE_MEMORY
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL ? 16 : 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL ? 16 : CVH_POL0_STORE_AUX);
 #else
   asm volatile("" :: "v"(v.x), "v"(v.y));
 #endif
