@@ -430,3 +430,23 @@ def test_error_paths(capi):
             ctx.perona_malik(10, 0.3, 20)           # L > 0.25, src/main.cpp:863
         with pytest.raises(capi.CvhError):
             ctx.set_option("nonsense", 1)
+
+
+@pytest.mark.parametrize("shape,channels,kernel", [((700, 1008), 1, 3), ((333, 500), 1, 2), ((200, 272), 3, 2)])
+def test_cache_policy_of_the_rows_does_not_change_results(capi, shape, channels, kernel):
+    """"wave_pol" selects write-through or plain stores (and sc0 or plain loads) for the streamed level-set rows: a template
+    parameter of the wave kernels that must not change a single bit of the level set, the trace or the means."""
+    h, w = shape
+    rng = np.random.default_rng(h + 7 * w + channels)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(channels)]
+    out = []
+    for pol in (0, 1, -1):
+        with capi.Context(h, w, channels, capi.make_params(tol=0.0)) as ctx:
+            ctx.set_option("kernel", kernel); ctx.set_option("wave_pol", pol); ctx.set_option("trace", 40)
+            ctx.set_image(planes); ctx.init_checkerboard()
+            ctx.enqueue_steps(21); ctx.enqueue_steps(16)
+            done, nrm, _ = ctx.sync()
+            out.append((ctx.get_levelset(), ctx.get_trace(40), done, nrm))
+    for o in out[1:]:
+        assert o[2] == out[0][2] == 37 and o[3] == out[0][3]
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
