@@ -321,7 +321,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value != 4 && value != 5) return fail(c, CVH_ERR_ARG, "far_terms must be 4 or 5");
     c->far_terms = (int)value;
   } else if (!strcmp(key, "wave_pol")) {
-    if (value < -1 || value > 1) return fail(c, CVH_ERR_ARG, "wave_pol must be -1 (auto), 0 or 1");
+    if (value < -1 || value > 2) return fail(c, CVH_ERR_ARG, "wave_pol must be -1 (auto), 0, 1 or 2 (diagnostic: non-temporal loads)");
     c->wave_pol = (int)value;
   } else if (!strcmp(key, "wave_cls")) {
     if (value < 0 || value > 2) return fail(c, CVH_ERR_ARG, "wave_cls must be 0 (off), 1 (2-pixel kernel) or 2 (1-pixel kernel too)");
@@ -1144,7 +1144,7 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   memset(&a, 0, sizeof(a));
   a.h = c->h; a.w = c->w; a.K2 = K * K; a.L = L;
   a.invK2 = 1.0 / (K * K); a.L4 = L / 4; a.fast = use_fast(c) ? 1 : 0;
-  a.pol = (c->wave_pol >= 0 ? c->wave_pol : ((double)c->n * 16.0 <= 300e6 ? 1 : 0));
+  a.pol = (c->wave_pol >= 0 ? (c->wave_pol == 1) : ((double)c->n * 16.0 <= 300e6 ? 1 : 0));
   // auto: the 2-pixel kernel for large planes (measured 50.4 vs 53.3 us/step at 4096^2, but 19 vs 15.7 at 2048^2:
   // its strips get too short there), the 1-pixel wave kernel otherwise
   const bool pm2_ok = c->w % 2 == 0 && c->w >= 128 && c->n < ((size_t)1 << 28);

@@ -398,5 +398,6 @@ hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s)
   if (!fast) return launch_wave2<false, 2, 1>(a, s);
   // default: 3 waves/SIMD with branch-free rows (measured 65.1 vs 66.3 us for 4 waves/SIMD with the per-row branch)
   if (a.wave_minw == 4) return launch_wave2<true, 4, 1>(a, s);
+  if (a.wave_pol == 2) return launch_wave2<true, 3, 2>(a, s);   // diagnostic: plain stores, non-temporal loads
   return a.wave_pol ? launch_wave2<true, 3, 1>(a, s) : launch_wave2<true, 3, 0>(a, s);   // cache policy of the rows: wave2_device.h
 }

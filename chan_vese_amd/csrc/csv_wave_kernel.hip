@@ -501,7 +501,7 @@ hipError_t launch_wave_g(const CvhStepArgs &a, hipStream_t s)
   const bool imgv = a.w % 16 == 0 && a.w >= 80 && a.wave_imgv;
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup of chain mode
   if constexpr (FAST && LUT && G == 1) {   // the shipped flavours exist with write-through stores too
-    if (a.wave_pol) {
+    if (a.wave_pol == 1) {
       if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G, 1>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
       else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G, 1>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
       return hipGetLastError();

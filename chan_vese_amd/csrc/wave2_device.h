@@ -44,14 +44,14 @@ __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, un
   const double v = __builtin_bit_cast(double, 0x4059000000000000ull | (unsigned long long)((voff + soff) & 0xffff));   // ~100: far field
   return double2_t{v, -v};
 #else
-  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL ? 1 : CVH_POL0_LOAD_AUX));
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL == 1 ? 1 : (POL == 2 ? 2 : CVH_POL0_LOAD_AUX)));   // POL 2 (diagnostic): nt loads
 #endif
 }
 template <int POL>
 __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
 #ifndef CVH_ABLATE_MEMORY
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL ? 16 : CVH_POL0_STORE_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL == 1 ? 16 : CVH_POL0_STORE_AUX);
 #else
   asm volatile("" :: "v"(v.x), "v"(v.y));
 #endif

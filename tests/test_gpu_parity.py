@@ -440,7 +440,7 @@ def test_cache_policy_of_the_rows_does_not_change_results(capi, shape, channels,
     rng = np.random.default_rng(h + 7 * w + channels)
     planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(channels)]
     out = []
-    for pol in (0, 1, -1):
+    for pol in (0, 1, -1, 2):
         with capi.Context(h, w, channels, capi.make_params(tol=0.0)) as ctx:
             ctx.set_option("kernel", kernel); ctx.set_option("wave_pol", pol); ctx.set_option("trace", 40)
             ctx.set_image(planes); ctx.init_checkerboard()
