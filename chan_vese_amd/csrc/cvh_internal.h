@@ -16,6 +16,7 @@
 //   "wave_imgv" 16-byte image pieces (1), "wave_xcd" XCD-contiguous workgroup numbering (1),
 //   "wave_skew" per-mille strip-length skew of the 1-pixel kernel (0), "wave_cls" class-major workgroup numbering (0 off,
 //   1 = 2-pixel kernel (default), 2 = 1-pixel kernel too), "wave_cskew" per-mille strip-length skew between dispatch rounds (500),
+//   "wave_pol" = 2 (diagnostic value of the public option: plain stores with non-temporal loads),
 //   "chain" fixed-point chained sums + deferred bookkeeping in the wave kernels (1), "far_terms" terms of the far-field series (5; 4), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
 //   read with cvh_debug_read, tools/wave_timeline.py).
 
