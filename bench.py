@@ -26,6 +26,8 @@ Prints ONE JSON line on rank 0 (the driver's contract) with extra objects:
   phases        (N=1) us per iteration over iterations 1-16 / 17-100 / 101-500 of a fresh run from the
                 checkerboard, one sync per segment, measured after the timed region
   pm            (C4) the Perona-Malik phase with its own roofline
+  checked       true once every resident image's result passed verify_result() AFTER the timed region (outside it): the
+                level set is finite, the mask is the synthetic disk (or its complement), c1/c2 sit at the disk's levels
 """
 import argparse
 import json
@@ -111,6 +113,48 @@ def resolve_workload(args, world):
     return name, n, C, images, steps, desc
 
 
+def expected_disk(name, n, gb):
+    """(boolean disk of image gb, [(fg, bg) per channel], noise amplitude) of the synthetic inputs (chan_vese_amd/synth.py)."""
+    import numpy as np
+    r = n // 4 + 8 * (gb % 8) - 28 if name in ("C5", "C5-image") else n // 4
+    ii = np.arange(n, dtype=np.int64)[:, None] - n // 2
+    jj = np.arange(n, dtype=np.int64)[None, :] - n // 2
+    disk = ii * ii + jj * jj <= r * r
+    levels = [(180, 40), (200, 60), (60, 200)] if name == "C3" else [(200, 50)]
+    noise = {"C4": 32, "C4-image": 32, "C5": 16, "C5-image": 16}.get(name, 0)
+    return disk, levels, noise
+
+
+def verify_result(name, n, gb, ctx, iterations):
+    """Property check of one image's result (no oracle: it cannot follow 500 iterations at 4096^2 in minutes).  The
+    Chan-Vese fixed point of a two-level disk image is the disk: mask == disk or its complement (which side is 'inside'
+    is decided by the sign of c1 - c2 after the first iteration of the symmetric checkerboard start), region means at the
+    disk's two levels, every level-set value finite.  Needs enough iterations for the checkerboard to dissolve."""
+    import numpy as np
+    disk, levels, noise = expected_disk(name, n, gb)
+    u = ctx.get_levelset()
+    mask = ctx.get_mask().astype(bool)
+    c1, c2 = ctx.get_means()
+    finite = bool(np.isfinite(u).all())
+    inter, union = (mask & disk).sum(), (mask | disk).sum()
+    iou_d = inter / max(union, 1)
+    inter_c, union_c = (mask & ~disk).sum(), (mask | ~disk).sum()
+    iou_c = inter_c / max(union_c, 1)
+    inside_is_disk = iou_d >= iou_c
+    iou = float(max(iou_d, iou_c))
+    # c1 = mean over the inside (H ~ 1): the disk's foreground if the inside is the disk, else the background; the smoothed
+    # Heaviside leaks ~1/(pi |u|) of the other region into each mean, the noise is zero-mean up to clamping
+    tol_c = 4.0 + 0.05 * noise      # oracle, 512^2 / noisy 2048^2: 2.7 / 3.4 after 5 iterations, 2.1 after 25, 1.6 after 64
+    dev = 0.0
+    for k, (fg, bg) in enumerate(levels):
+        want1, want2 = (fg, bg) if inside_is_disk else (bg, fg)
+        dev = max(dev, abs(c1[k] - want1), abs(c2[k] - want2))
+    settled = iterations >= 5       # oracle: the mask IS the disk from iteration 5 on (512^2 clean, 2048^2 noise 32)
+    ok = finite and (not settled or (iou >= 0.999 and dev <= tol_c))
+    return ok, {"image": gb, "finite": finite, "mask_iou_vs_disk": iou, "inside_is_disk": bool(inside_is_disk),
+                "max_abs_c_minus_level": float(dev)}
+
+
 def image_planes(name, n, gb):
     from chan_vese_amd import synth
     if name == "C3":
@@ -183,7 +227,7 @@ def main():
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": pm_bytes * trips / (pm_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_launch": pm_bytes, "traffic": None,
-                                        "kernel": "pm_wave_k2_kernel (2 time steps per launch)", "steps_per_launch": 2}}
+                                        "kernel": None, "steps_per_launch": None}}   # filled from cvh_launch_info below
             ctx.init_checkerboard()
             ctxs.append(ctx)
 
@@ -253,10 +297,24 @@ def main():
         kernel_ms = [ctx.last_run_ms() for ctx in ctxs]  # HIP events on each image's stream
         assert all(r[0] == args.warmup + steps and not r[2] for r in res), res
 
+    # result check, outside the timed region: every resident image (the 8 interleaved C5 images included)
+    checked, check_info, launch, pm_launch = None, [], None, None
+    if not dry:
+        checked = True
+        for b, ctx in enumerate(ctxs):
+            ok, info = verify_result(name, n, rank * images + b, ctx, args.warmup + steps)
+            check_info.append(info)
+            checked = checked and ok
+        if not checked:     # reported after the collectives below (a rank that left early would hang the others)
+            print(f"bench.py: result check FAILED on rank {rank}: {check_info}", file=sys.stderr, flush=True)
+        launch = ctxs[0].launch_info(0)
+        pm_launch = ctxs[0].launch_info(1) if pm_info is not None else None
+
     # end-of-run gather of the per-rank records (the only collective besides barriers/max)
-    records = batch.gather_records(dist, [images, float(n) * n * steps * images, elapsed])
+    records = batch.gather_records(dist, [images, float(n) * n * steps * images, elapsed, 0.0 if checked is False else 1.0])
     elapsed = batch.max_over_ranks(dist, elapsed)
     value = batch.aggregate_throughput(records, elapsed)
+    all_checked = all(r[3] == 1.0 for r in records)
 
     out = None
     if rank == 0:
@@ -273,13 +331,20 @@ def main():
                 traffic = tj.get(f"csv_step_{n}x{n}x{C}")
                 traffic_source = tj.get("_source") if traffic is not None else None
                 if pm_info is not None and tj.get(f"pm_2steps_{n}x{n}x{C}") is not None:
-                    pm_info["roofline"]["traffic"] = tj[f"pm_2steps_{n}x{n}x{C}"] / 2.0   # per time step (a launch makes two)
+                    if pm_launch is not None and int(pm_launch["steps_per_launch"]) == 2:   # the counters were taken on the 2-step kernel
+                        pm_info["roofline"]["traffic"] = tj[f"pm_2steps_{n}x{n}x{C}"] / 2.0   # per time step (a launch makes two)
                     pm_info["roofline"]["traffic_source"] = tj.get("_source")
             except Exception:
                 traffic = None
-        kopt = dict(kv.split("=") for kv in (args.opt or [])).get("kernel", "-1")
-        two_px = C == 1 and n % 16 == 0 and n >= 144 and (kopt == "3" or (kopt == "-1" and n * n >= 600000))   # api.hip resolve_geometry
-        kernel_name = {"0": "csv_step_kernel (tile)", "1": "csv_strip_kernel"}.get(kopt, "csv_wave2_kernel" if two_px else "csv_wave_kernel")
+        kernel_name = launch["kernel"] if not dry else "none (dry run)"     # what the library says it launches (cvh_launch_info)
+        # the same bytes over the WALL clock `value` is computed from (max over ranks, all images of a rank): frac_wall;
+        # over the HIP events on the kernel's stream: frac_events (= frac, the contract's definition)
+        wall_launch_s = max(elapsed / max(steps, 1) / images, 1e-12)
+        frac_wall = bytes_per_launch / wall_launch_s / 1e9 / HBM_PEAK_GBS
+        if pm_info is not None and pm_launch is not None:
+            pm_info["roofline"]["kernel"] = pm_launch["kernel"]
+            pm_info["roofline"]["steps_per_launch"] = int(pm_launch["steps_per_launch"])
+            pm_info["roofline"]["launch_info"] = pm_launch
         workload = f"{name}: {n}x{n} {C}-channel {desc}, checkerboard init, {steps} CSV iterations after {args.warmup} warm-up, tol 0"
         out = {
             "metric": "Mpixel-iterations/s (CSV u-update)",
@@ -301,9 +366,15 @@ def main():
                        "backend": (dist.get_backend() if dist is not None else "none"),
                        "per_rank_mpx_it_s": [r[1] / r[2] / 1e6 for r in records]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel_name, "avg_launch_us": avg_launch_s * 1e6,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_clock": "hip_events",
+                         "frac_events": achieved / HBM_PEAK_GBS, "frac_wall": frac_wall,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name, "launch_info": (launch if not dry else None), "avg_launch_us": avg_launch_s * 1e6,
+                         "avg_launch_us_wall": wall_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
+            "checked": (all_checked if not dry else None),
+            "check": {"what": "after the timed region: level set finite, mask IoU vs the synthetic disk (or its complement) >= 0.999, "
+                              "|c1/c2 - disk level| small; every resident image", "images": check_info},
         }
         if pm_info is not None:
             out["pm"] = pm_info
@@ -334,6 +405,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not all_checked:
+        sys.exit("bench.py: a result check failed (see stderr of the rank): no line is printed for a wrong result")
     if out is not None:
         print(json.dumps(out), flush=True)
 

@@ -24,7 +24,9 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    # CHANVESE_DIST_FORCE=1: build the process group even for ONE rank (the RCCL path on a one-GPU box:
+    # tests/test_gpu_fullsize.py::test_bench_one_rank_over_rccl); MASTER_ADDR / MASTER_PORT must be set
+    if world == 1 and os.environ.get("CHANVESE_DIST_FORCE") != "1":
         return None, 0, 1, 0
     import torch
     import torch.distributed as dist

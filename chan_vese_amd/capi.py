@@ -25,7 +25,7 @@ EXPORTS = [
     "cvh_enqueue_steps", "cvh_warm", "cvh_sync", "cvh_reset_run", "cvh_get_means", "cvh_get_trace",
     "cvh_get_stop_condition", "cvh_get_mask", "cvh_get_contour", "cvh_separate", "cvh_perona_malik",
     "cvh_pm_trip_count", "cvh_last_run_ms", "cvh_last_pm_ms", "cvh_ppf_apply",
-    "cvh_ppf_apply_device", "cvh_version",
+    "cvh_ppf_apply_device", "cvh_version", "cvh_launch_info",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
         "cvh_ppf_apply": (C.c_int, [dp, C.c_int, C.c_long, C.c_long, C.c_int, C.c_double, C.c_int]),
         "cvh_ppf_apply_device": (C.c_int, [dp, C.c_long, C.c_int, C.c_double, vp]),
         "cvh_version": (C.c_char_p, []),
+        "cvh_launch_info": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -276,6 +277,21 @@ class Context:
         v = C.c_float(0.0)
         self._chk(self._L.cvh_last_run_ms(self._h, C.byref(v)))
         return v.value
+
+    def launch_info(self, phase=0):
+        """What the library launches (phase 0: the CSV step with the current options; 1: the last Perona-Malik call) as a
+        dict of the key=value pairs cvh_launch_info writes; "kernel" is the instantiation as rocprofv3 prints it."""
+        buf = C.create_string_buffer(512)
+        self._chk(self._L.cvh_launch_info(self._h, int(phase), buf, len(buf)))
+        out = {}
+        for tok in buf.value.decode().split(" "):
+            if "=" in tok:
+                k, v = tok.split("=", 1)
+                out[k] = v
+            elif out:                       # template arguments are separated by ", "
+                last = next(reversed(out))
+                out[last] += " " + tok
+        return out
 
     def last_pm_ms(self):
         v = C.c_float(0.0)

@@ -44,7 +44,9 @@ struct cvh_context {
   double *d_dummy = nullptr;
   int wave_rev = 0, wave_xcd = 1;
   int use_graph = 1;
-  StepGraph graphs[2];          // by ping-pong parity of the first step
+  StepGraph graphs[4];          // by the chain-mode sum set of the first step, (chain_pb + enqueued) & 3; the ping-pong parity
+                                // follows it (cur_base == chain_pb mod 2: set_levelset / init_checkerboard keep that invariant)
+  char pm_desc[256] = {0};      // what the last cvh_perona_malik launched (cvh_launch_info)
   hipGraphExec_t pm_graph = nullptr;   // 16 Perona-Malik steps starting from d_pm[0]
   CvhPmArgs pm_graph_key{};
   int pm_graph_kind = -1;
@@ -108,6 +110,15 @@ static bool use_fast(const cvh_context *c)
 
 extern "C" const char *cvh_version(void) { return "chanvese_hip 0.1 (gfx950)"; }
 
+void cvh_fill_note(CvhLaunchNote *note, unsigned grid, unsigned block, size_t lds, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(note->name, sizeof(note->name), fmt, ap);
+  va_end(ap);
+  note->grid = grid; note->block = block; note->lds = (unsigned)lds;
+}
+
 extern "C" void cvh_default_params(cvh_params *p)
 {
   if (!p) return;
@@ -154,7 +165,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_mask) (void)hipFree(c->d_mask);
   if (c->d_atan) (void)hipFree(c->d_atan);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
-  for (int k = 0; k < 2; ++k) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
+  for (int k = 0; k < 4; ++k) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->pm_graph) (void)hipGraphExecDestroy(c->pm_graph);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
   if (c->d_chain) (void)hipFree(c->d_chain);
@@ -477,8 +488,10 @@ extern "C" int cvh_set_levelset(cvh_context *c, const double *u)
   HIPCHK(c, hipSetDevice(c->device));
   if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->cur_base = 0; c->steps_done = 0; c->enqueued = 0;
-  HIPCHK(c, hipMemcpyAsync(c->d_u[0], u, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // the new level set goes into the buffer whose parity equals the chain-mode sum set's (chain_pb & 1): the ping-pong parity
+  // and the sum-set phase of a launch then stay locked together, and a cached step graph of a phase is valid for every run
+  c->cur_base = c->chain_pb & 1; c->steps_done = 0; c->enqueued = 0;
+  HIPCHK(c, hipMemcpyAsync(c->d_u[c->cur_base], u, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_u = true;
   c->sums_valid = false;
@@ -512,9 +525,9 @@ extern "C" int cvh_init_checkerboard(cvh_context *c)
   const double pi = 3.14159265358979323846;
   for (int i = 0; i < c->h; ++i) sv[i] = sin(pi * i / 5);
   for (int j = 0; j < c->w; ++j) sv[(size_t)c->h + j] = sin(pi * j / 5);
-  c->cur_base = 0; c->steps_done = 0; c->enqueued = 0;
-  HIPCHK(c, hipMemcpyAsync(c->d_u[1], sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, cvh_launch_checkerboard(c->d_u[1], c->d_u[0], c->h, c->w, c->stream));
+  c->cur_base = c->chain_pb & 1; c->steps_done = 0; c->enqueued = 0;   // see cvh_set_levelset
+  HIPCHK(c, hipMemcpyAsync(c->d_u[c->cur_base ^ 1], sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, cvh_launch_checkerboard(c->d_u[c->cur_base ^ 1], c->d_u[c->cur_base], c->h, c->w, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_u = true;
   c->sums_valid = false;
@@ -545,7 +558,9 @@ static Geometry resolve_geometry(const cvh_context *c)
   // auto: the 2-pixel kernel from 0.6 Mpixel up (end of round 2, one context per size, 2-pixel with its cache policy chosen by
   // footprint vs 1-pixel: 3000x4000 40.3 vs 43.8 us, 4096^2 59.4 vs 64.7, 4608^2 80.5 vs 87.2, 5120^2 93.1 vs 97.2, 6144^2 133.0 vs
   // 140.7, 4320x7680 122.7 vs 123.2, 8192^2 243.3 vs 245.5)
-  if ((c->kernel == 3 || (c->kernel == -1 && c->n >= (size_t)600000)) && c->C == 1 && c->w % 16 == 0 && c->w >= 144 &&
+  // three channels: the 2-pixel flavour exists in FAST arithmetic only, on request ("kernel" = 3) until it is measured faster
+  const bool two_px_c3 = c->C == 3 && use_fast(c) && c->kernel == 3;
+  if ((c->kernel == 3 || (c->kernel == -1 && c->n >= (size_t)600000)) && (c->C == 1 || two_px_c3) && c->w % 16 == 0 && c->w >= 144 &&
       c->n < ((size_t)1 << 28)) {
     // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
     // one round of resident waves (3 or 4 per SIMD)
@@ -818,18 +833,24 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
   return CVH_OK;
 }
 
-static int launch_one_step(cvh_context *c, int in_buf, int step)
+// `capturing`: the launch is recorded into a stream capture, nothing reaches the GPU -- the context's bookkeeping of what is
+// in flight (chain_pending, chain_acc_valid) is updated by the caller when the graph is really launched
+static int launch_one_step(cvh_context *c, int in_buf, int step, bool capturing = false, CvhLaunchNote *note = nullptr)
 {
   CvhStepArgs a;
   fill_args(c, &a, in_buf, step);
+  a.note = note;
   const int kind = resolve_geometry(c).strip;
-  if (kind == 3) HIPCHK(c, cvh_launch_wave2(a, use_fast(c), c->stream));
+  if (kind == 3) HIPCHK(c, cvh_launch_wave2(a, c->C, use_fast(c), c->stream));
   else if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
   else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
   else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
+  if (note) return CVH_OK;
   if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
-  if (a.chain) c->chain_pending = true;
-  else c->chain_acc_valid = false;   // the means now live in the state block only
+  if (!capturing) {
+    if (a.chain) c->chain_pending = true;
+    else c->chain_acc_valid = false;   // the means now live in the state block only
+  }
   return CVH_OK;
 }
 
@@ -852,16 +873,22 @@ static int chain_flush(cvh_context *c)
 // The instantiated graph is kept per start parity and rebuilt when any launch argument changed.
 static int ensure_step_graph(cvh_context *c, int parity)
 {
-  StepGraph &g = c->graphs[parity];
+  // One slot per sum-set phase of the first step: a chunk size that is not a multiple of 4 (sync_every = 18, repeated
+  // cvh_enqueue_steps(18), a run that stopped early) cycles through the phases, and each keeps its instantiated graph.
+  StepGraph &g = c->graphs[(c->chain_pb + c->enqueued) & 3];
   // the arguments of consecutive steps differ in the ping-pong parity and the chain-mode sum set: period 4
   CvhStepArgs key[4];
   for (int s = 0; s < 4; ++s) fill_args(c, &key[s], parity ^ (s & 1), c->enqueued + s);
   const int kind = resolve_geometry(c).strip, flavour = (use_fast(c) ? 1 : 0) | (c->finalize_mode << 1);
   if (g.exec && g.kind == kind && g.flavour == flavour && !memcmp(key, g.key, sizeof(key))) return CVH_OK;
-  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  if (g.exec) {   // an argument changed: the old exec may still have launches in flight (cvh_run queues chunks ahead)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+  }
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = CVH_OK;
-  for (int s = 0; s < kGraphSteps && rc == CVH_OK; ++s) rc = launch_one_step(c, parity ^ (s & 1), c->enqueued + s);
+  for (int s = 0; s < kGraphSteps && rc == CVH_OK; ++s) rc = launch_one_step(c, parity ^ (s & 1), c->enqueued + s, true);
   hipGraph_t graph = nullptr;
   const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
   if (rc != CVH_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -913,8 +940,9 @@ static int enqueue_impl(cvh_context *c, int nsteps)
     const int parity = (c->cur_base + c->enqueued) & 1;
     const int rc = ensure_step_graph(c, parity);
     if (rc != CVH_OK) return rc;
-    HIPCHK(c, hipGraphLaunch(c->graphs[parity].exec, c->stream));
-    if (c->graphs[parity].key[0].chain) c->chain_pending = true; else c->chain_acc_valid = false;
+    const StepGraph &sg = c->graphs[(c->chain_pb + c->enqueued) & 3];
+    HIPCHK(c, hipGraphLaunch(sg.exec, c->stream));
+    if (sg.key[0].chain) c->chain_pending = true; else c->chain_acc_valid = false;
     c->enqueued += kGraphSteps;
     s += kGraphSteps;
   }
@@ -1197,11 +1225,22 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
     return kind == 2 ? cvh_launch_pm_wave2(pa, c->stream) : (kind == 1 ? cvh_launch_pm_wave(pa, c->stream) : cvh_launch_pm_step(pa, c->stream));
   };
   const int per_launch = pm_k2 ? 2 : 1;   // time steps per launch of the bulk kernel
-  auto launch_bulk = [&](int from) -> hipError_t {
-    if (!pm_k2) { CvhPmArgs pa = a; pa.in = c->d_pm[from]; pa.out = c->d_pm[from ^ 1]; return launch_pm(pa); }
-    CvhPmArgs pa = a2; pa.in = c->d_pm[from]; pa.out = c->d_pm[from ^ 1];
+  auto launch_bulk = [&](int from, CvhLaunchNote *note = nullptr) -> hipError_t {
+    if (!pm_k2) { CvhPmArgs pa = a; pa.in = c->d_pm[from]; pa.out = c->d_pm[from ^ 1]; pa.note = note; return launch_pm(pa); }
+    CvhPmArgs pa = a2; pa.in = c->d_pm[from]; pa.out = c->d_pm[from ^ 1]; pa.note = note;
     return cvh_launch_pm_wave_k2(pa, c->stream);
   };
+  {   // what this call launches, for cvh_launch_info (filled by the launch sites themselves)
+    CvhLaunchNote nb{}, no{};
+    (void)launch_bulk(0, &nb);
+    const bool odd = trips % per_launch != 0;
+    if (odd) { CvhPmArgs pa = a; pa.in = c->d_pm[0]; pa.out = c->d_pm[1]; pa.note = &no; (void)launch_pm(pa); }
+    const bool graphed = c->use_graph && trips >= kGraphSteps * per_launch;
+    snprintf(c->pm_desc, sizeof(c->pm_desc),
+             "kernel=%s grid=%u block=%u steps_per_launch=%d strip_rows=%d launches=%d%s%s graph_launches=%d trips=%d planes=%d",
+             nb.name, nb.grid, nb.block, per_launch, pm_k2 ? a2.strip_rows : a.strip_rows, trips / per_launch,
+             odd ? " last_step_kernel=" : "", odd ? no.name : "", graphed ? kGraphSteps : 0, trips, c->C);
+  }
   // kGraphSteps steps as one hipGraph, as for the CSV step: a graph node costs 1.6 us against 2.8 us for a stream launch
   // (tools/launch_probe.hip) and a 2048^2 step is only ~13 us.  The graph always starts from d_pm[0] (16 is even).
   if (c->use_graph && trips >= kGraphSteps * per_launch) {
@@ -1303,6 +1342,27 @@ extern "C" int cvh_ppf_apply(double *data, int w, long start, long end, int op, 
   if (pooled) { (void)hipFreeAsync(d, st); (void)hipStreamSynchronize(st); } else (void)hipFree(d);
   (void)hipStreamDestroy(st);
   if (e != hipSuccess) return fail(nullptr, CVH_ERR_HIP, "cvh_ppf_apply: %s", hipGetErrorString(e));
+  return CVH_OK;
+}
+
+extern "C" int cvh_launch_info(cvh_context *c, int phase, char *buf, int cap)
+{
+  if (!c || !buf || cap < 1 || (phase != 0 && phase != 1)) return CVH_ERR_ARG;
+  if (phase == 1) {
+    if (!c->pm_desc[0]) return fail(c, CVH_ERR_STATE, "cvh_launch_info: cvh_perona_malik has not run on this context");
+    snprintf(buf, (size_t)cap, "%s", c->pm_desc);
+    return CVH_OK;
+  }
+  // the CSV step as the next cvh_run / cvh_enqueue_steps would launch it: the launcher itself describes it (CVH_LAUNCH)
+  CvhLaunchNote note{};
+  const int rc = launch_one_step(c, current_buffer(c), c->enqueued, true, &note);
+  if (rc != CVH_OK) return rc;
+  const Geometry g = resolve_geometry(c);
+  CvhStepArgs a;
+  fill_args(c, &a, current_buffer(c), c->enqueued);
+  snprintf(buf, (size_t)cap, "kernel=%s grid=%u block=%u lds_bytes=%u data_flow=%d wave_columns=%d strips=%d strip_rows=%d chain=%d "
+           "wave_pol=%d math=%s steps_per_graph=%d", note.name, note.grid, note.block, note.lds, g.strip, g.tiles_x, g.tiles_y,
+           g.strip_rows, a.chain ? 1 : 0, a.wave_pol, use_fast(c) ? "fast" : "strict", c->use_graph ? kGraphSteps : 0);
   return CVH_OK;
 }
 

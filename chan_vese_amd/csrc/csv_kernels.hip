@@ -295,12 +295,12 @@ hipError_t launch_step_v(const CvhStepArgs &a, hipStream_t s)
 {
   using L = StepSmem<C, R, FAST, LUT>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
-  const dim3 grid(a.tiles_x * a.tiles_y), block(CVH_BLOCK);
+  const int grid = a.tiles_x * a.tiles_y;
   // the LDS-DMA loader needs 16-byte aligned rows: even width (hipMalloc bases are aligned)
   if (a.use_dma && (a.w % 2 == 0) && a.w >= 2)
-    hipLaunchKernelGGL((csv_step_kernel<C, R, FAST, LUT, true>), grid, block, L::bytes, s, a);
+    CVH_LAUNCH((csv_step_kernel<C, R, FAST, LUT, true>), grid, L::bytes, s, a, "csv_step_kernel<%d, %d, %s, %s, true>", C, R, CVH_TF(FAST), CVH_TF(LUT));
   else
-    hipLaunchKernelGGL((csv_step_kernel<C, R, FAST, LUT, false>), grid, block, L::bytes, s, a);
+    CVH_LAUNCH((csv_step_kernel<C, R, FAST, LUT, false>), grid, L::bytes, s, a, "csv_step_kernel<%d, %d, %s, %s, false>", C, R, CVH_TF(FAST), CVH_TF(LUT));
   return hipGetLastError();
 }
 

@@ -301,7 +301,7 @@ hipError_t launch_strip_v(const CvhStepArgs &a, hipStream_t s)
   using L = StripSmem<C, R, FAST, LUT>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
   const int nseg = (a.h + a.strip_rows - 1) / a.strip_rows;
-  hipLaunchKernelGGL((csv_strip_kernel<C, R, FAST, LUT>), dim3(a.tiles_x * nseg), dim3(CVH_BLOCK), L::bytes, s, a);
+  CVH_LAUNCH((csv_strip_kernel<C, R, FAST, LUT>), a.tiles_x * nseg, L::bytes, s, a, "csv_strip_kernel<%d, %d, %s, %s>", C, R, CVH_TF(FAST), CVH_TF(LUT));
   return hipGetLastError();
 }
 

@@ -12,6 +12,10 @@
 //   the BORDER_REPLICATE clamps at the image's left / right edges, so the row values need no selects.
 // Workgroup = 2 wave-columns x 2 strips (a 4096-wide image has 33 wave-columns: pairs waste less than
 // quads).  Requires w % 16 == 0 and w >= 144 (16-byte image pieces); other shapes use kernel 2.
+// C = 3 (round 3, FAST only): one image tile per channel (two piece loads per group), the samples are read from the
+// tile inside the row (no per-group sample registers), and the region term sum_k [l2k (I_k - c2k)^2 - l1k (I_k - c1k)^2] beta
+// + gamma is either three table lookups (POLY false) or, with POLY, the quadratic sum_k (qa_k I_k + qb_k) I_k + qc with
+// seven wave-uniform coefficients -- no table fill, no 16-byte LDS returns (rounding moves by a few ulp of the term)
 #include "csv_device.h"
 #include "buffer_ops.h"
 #include "wave_math.h"
@@ -23,11 +27,14 @@ using namespace cvh_dev;
 
 namespace {
 
-template <bool FAST, int MINW, int POL>
+template <int C, bool FAST, int MINW, int POL, bool POLY>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhStepArgs a)
 {
-  using L = Wave2Smem<FAST>;
-  constexpr int NS = NS2, R = R2;
+  static_assert(C == 1 || FAST, "the 3-channel flavour exists in FAST arithmetic only (STRICT: kernel 2)");
+  static_assert(!POLY || C == 3, "POLY is the 3-channel region term");
+  using L = Wave2Smem<FAST, C, !POLY>;
+  constexpr int NS = cvh_nsums(C), R = R2;
+  constexpr int NIQ = (9 * R * C + 63) / 64;   // image piece loads per group (9 pieces x R rows x C channels, one lane each)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *sred = smem + L::off_red;
   double *sfin = smem + L::off_fin;
@@ -83,23 +90,55 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   // region means of the level set this launch reads: from the fixed-point sum set (chain mode: one 8-byte load per
   // lane, in flight beside the first rows of u) or from the state block the last finaliser wrote
   double c1, c2;
+  double cm1[C], cm2[C];                    // C = 3: the region means per channel
+  double qa[C], qb[C], qc = 0.0;            // POLY: coefficients of the quadratic region term (wave-uniform)
   long long chain_entry = 0;
   if (chain) chain_entry = a.chain->v[a.chain_phase][lane];
-  else { c1 = a.st->c1[0]; c2 = a.st->c2[0]; }
-  if (bookkeeper) { chain_bookkeeper_block<1>(a, chain_entry, sred); return; }
+  else if (C == 1) { c1 = a.st->c1[0]; c2 = a.st->c2[0]; }
+  else {
+#pragma unroll
+    for (int k = 0; k < C; ++k) { cm1[k] = a.st->c1[k]; cm2[k] = a.st->c2[k]; }
+  }
+  if (bookkeeper) { chain_bookkeeper_block<C>(a, chain_entry, sred); return; }
   const double l1 = a.lambda1[0], l2 = a.lambda2[0];
   const double eps = a.eps, eps2 = eps * eps;
   const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_k[4], a.far_thr};
 
   auto fill_tables = [&]() {
-    if (chain) { double m1[1], m2[1]; chain_means<1>(a, chain_entry, m1, m2); c1 = m1[0]; c2 = m2[0]; }
-    if (FAST) {
+    if (C == 1) {
+      if (chain) { double m1[1], m2[1]; chain_means<1>(a, chain_entry, m1, m2); c1 = m1[0]; c2 = m2[0]; }
+      if (FAST) {
+        for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
+        const double v = (double)tid;
+        const double d1 = v - c1, d2 = v - c2;
+        const double reg = (d2 * d2) * l2 - (d1 * d1) * l1;
+        slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
+        slut[2 * tid + 1] = v;
+      }
+    } else {
+      if (chain) chain_means<C>(a, chain_entry, cm1, cm2);
       for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
-      const double v = (double)tid;
-      const double d1 = v - c1, d2 = v - c2;
-      const double reg = (d2 * d2) * l2 - (d1 * d1) * l1;
-      slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
-      slut[2 * tid + 1] = v;
+      if (POLY) {
+        // sum_k [l2k (I - c2k)^2 - l1k (I - c1k)^2] beta + gamma = sum_k (qa_k I + qb_k) I + qc   (:307-310, :979, :985)
+        qc = a.gamma;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const double k1 = a.lambda1[k], k2 = a.lambda2[k];
+          qa[k] = read_lane((k2 - k1) * a.beta, 0);
+          qb[k] = read_lane(-2.0 * a.beta * (k2 * cm2[k] - k1 * cm1[k]), 0);
+          qc = __builtin_fma(a.beta, k2 * cm2[k] * cm2[k] - k1 * cm1[k] * cm1[k], qc);
+        }
+        qc = read_lane(qc, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const double v = (double)tid;
+          const double d1 = v - cm1[k], d2 = v - cm2[k];
+          const double reg = (d2 * d2) * a.lambda2[k] - (d1 * d1) * a.lambda1[k];
+          slut[2 * (k * 256 + tid)] = (k == 0) ? __builtin_fma(reg, a.beta, a.gamma) : reg * a.beta;
+          slut[2 * (k * 256 + tid) + 1] = v;   // the sample as a double rides along (saves the conversion)
+        }
+      }
     }
   };
 
@@ -154,27 +193,57 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     const unsigned voff_i = (unsigned)(ilane ? irow : 0) * (unsigned)w + (unsigned)ipc;
     unsigned char *ipiece_dst = simg + irow * IMGP2 + ((icol0 + 16 * ipiece) == ipc ? 16 * ipiece : ipc - icol0);
     const int ibyte = cl - icol0;                               // bytes of (a, b): ibyte, ibyte + 1
-    const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[0], (unsigned)h * (unsigned)w);
+    const __amdgpu_buffer_rsrc_t ri = make_rsrc(a.img[0], (unsigned)(C - 1) * a.img_stride + (unsigned)h * (unsigned)w);
     auto IMQ = [&](int r0) -> u32x4_t {
       if (r0 + R - 1 <= ilast) return buf_load_b128(ri, voff_i, (unsigned)r0 * (unsigned)w);
       return buf_load_b128(ri, (unsigned)clampi(r0 + (ilane ? irow : 0), 0, ilast) * (unsigned)w + (unsigned)ipc, 0u);
+    };
+    // C = 3: piece q = 36 ch + 9 row + piece of the group's 108; load j fetches pieces 64 j + lane (the planes live in one slab)
+    bool q_on[NIQ];
+    int q_row[NIQ];
+    unsigned q_voff[NIQ], q_voff_cl[NIQ];     // interior offset (row folded in); channel + column part for the clamped form
+    unsigned char *q_dst[NIQ];
+#pragma unroll
+    for (int j = 0; j < NIQ; ++j) {
+      const int q = 64 * j + lane, qc = q < 9 * R * C ? q : 0;
+      const int ch = qc / (9 * R), il = qc % (9 * R), pr = il / 9, pp = il % 9;
+      int pcq = icol0 + 16 * pp;
+      pcq = pcq < 0 ? 0 : (pcq > w - 16 ? w - 16 : pcq);
+      q_on[j] = q < 9 * R * C;
+      q_row[j] = pr;
+      q_voff_cl[j] = (unsigned)ch * a.img_stride + (unsigned)pcq;
+      q_voff[j] = q_voff_cl[j] + (unsigned)pr * (unsigned)w;
+      q_dst[j] = simg + (ch * R + pr) * IMGP2 + ((icol0 + 16 * pp) == pcq ? 16 * pp : pcq - icol0);
+    }
+    auto IMQ3 = [&](int r0, int j) -> u32x4_t {
+      if (r0 + R - 1 <= ilast) return buf_load_b128(ri, q_voff[j], (unsigned)r0 * (unsigned)w);
+      return buf_load_b128(ri, q_voff_cl[j] + (unsigned)clampi(r0 + q_row[j], 0, ilast) * (unsigned)w, 0u);
     };
     auto lds_fence = [&]() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    int im[R];   // the group's samples: byte of a | byte of b << 8
-    auto park = [&](const double2_t (&T)[R], double X, u32x4_t IQ) {
+    int im[R];   // the group's samples: byte of a | byte of b << 8   (C = 1; three channels read them inside the row)
+    auto park = [&](const double2_t (&T)[R], double X, const u32x4_t (&IQ)[NIQ]) {
       lds_fence();
 #pragma unroll
       for (int j = 0; j < R; ++j) x_put[j * (XP2 / 2)] = T[j];
       *x_ext = X;
-      if (ilane) *reinterpret_cast<u32x4_t *>(ipiece_dst) = IQ;
-      lds_fence();
+      if (C == 1) {
+        if (ilane) *reinterpret_cast<u32x4_t *>(ipiece_dst) = IQ[0];
+      } else {
 #pragma unroll
-      for (int k = 0; k < R; ++k) im[k] = (int)*reinterpret_cast<const unsigned short *>(simg + k * IMGP2 + ibyte);
+        for (int j = 0; j < NIQ; ++j) if (q_on[j]) *reinterpret_cast<u32x4_t *>(q_dst[j]) = IQ[j];
+      }
+      lds_fence();
+      if (C == 1) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) im[k] = (int)*reinterpret_cast<const unsigned short *>(simg + k * IMGP2 + ibyte);
+      }
     };
+    // samples of row k of the group, channel ch: byte of a | byte of b << 8
+    auto samples = [&](int ch, int k) -> int { return (int)*reinterpret_cast<const unsigned short *>(simg + (ch * R + k) * IMGP2 + ibyte); };
 
     // ---- prologue
     const double2_t um2 = U(s0 - 2);
@@ -186,7 +255,12 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       for (int j = 0; j < R; ++j) T[j] = U(s0 + 1 + j);
       const double X0 = UX(s0);
       const double X = UX(s0 + 1);
-      const u32x4_t IQ = IMQ(s0);
+      u32x4_t IQ[NIQ];
+      if (C == 1) IQ[0] = IMQ(s0);
+      else {
+#pragma unroll
+        for (int j = 0; j < NIQ; ++j) IQ[j] = IMQ3(s0, j);
+      }
       fill_tables();
       __syncthreads();
       x_put[0] = u0;
@@ -235,6 +309,39 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       return c + ud;                                                   // :994
     };
 
+    // three channels (FAST): the same update with the region term summed over the channels (:965-985)
+    auto pixel3 = [&](double c, double n_, double s_, double nx, double nxl, double fx, double &nyp, const int (&byte)[C],
+                      double &ud_out, double (&Ik)[C]) -> double {
+      const double ny = norm(s_, n_, c);
+      const double kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
+      double reg;
+      if (POLY) {
+        reg = qc;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          Ik[ch] = (double)byte[ch];
+          reg = __builtin_fma(__builtin_fma(qa[ch], Ik[ch], qb[ch]), Ik[ch], reg);
+        }
+      } else {
+        const double2_t *lut2 = reinterpret_cast<const double2_t *>(slut);
+        const double2_t e0 = lut2[byte[0]];
+        reg = e0.x; Ik[0] = e0.y;
+#pragma unroll
+        for (int ch = 1; ch < C; ++ch) {
+          const double2_t e = lut2[ch * 256 + byte[ch]];
+          reg += e.x; Ik[ch] = e.y;
+        }
+      }
+      double ud = __builtin_fma(kappa, a.alpha, reg);                  // :985
+      const double qd = __builtin_fma(c, c, eps2) * a.dk1;             // 1/delta_eps(u)
+      const double r0 = __builtin_amdgcn_rcp(qd);
+      const double er = __builtin_fma(-qd, r0, 1.0);
+      ud = ud * __builtin_fma(__builtin_fma(er, er, er), r0, r0);      // :992
+      nyp = ny;
+      ud_out = ud;
+      return c + ud;                                                   // :994
+    };
+
     // DEFER (3 waves/SIMD: register room): rows without a branch, see csv_wave_kernel.hip
     constexpr bool DEFER = FAST && MINW <= 3;
     double2_t keep[R];
@@ -242,7 +349,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     auto row = [&](int i, int k, bool live) {
       const double2_t up = x_own[k * (XP2 / 2)];
       const double uw_n = x_w[k * XP2], ue_n = x_e[k * XP2];
-      const int ba = im[k] & 0xff, bb = (im[k] >> 8) & 0xff;
+      int sa[C], sb[C];                              // samples of pixel a / b per channel
+      if (C == 1) { sa[0] = im[k] & 0xff; sb[0] = (im[k] >> 8) & 0xff; }
+      else {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) { const int s = samples(ch, k); sa[ch] = s & 0xff; sb[ch] = s >> 8; }
+      }
+      const int ba = sa[0], bb = sb[0];
 #ifdef CVH_ABLATE_COMPUTE
       {   // keeps every load, LDS exchange and the store; no arithmetic
         keep[k] = double2_t{u0.x + (up.x + um.x + uw) * 1e-30 + (double)ba * 1e-30, u0.y + (up.y + um.y + ue) * 1e-30 + (double)bb * 1e-30};
@@ -258,8 +371,15 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       const double nxb = norm(ue, u0.x, u0.y);       // east = lane+1's a, west = own a
       const double nxla = dpp_from_left(nxb);
       double uda, udb, Ia, Ib, nya = nypa, nyb = nypb;
-      const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nya, ba, uda, Ia);
-      const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, bb, udb, Ib);
+      double Ika[C], Ikb[C];
+      double va, vb;
+      if (C == 1) {
+        va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nya, ba, uda, Ia);
+        vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, bb, udb, Ib);
+      } else {
+        va = pixel3(u0.x, um.x, up.x, nxa, nxla, fxa, nya, sa, uda, Ika);
+        vb = pixel3(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, sb, udb, Ikb);
+      }
       double hva, hvb;
       // gfx950 hazard (found in round 2, tools/dbg_occ4b.py): under memory back-pressure a 16-byte buffer store reads its
       // data registers long after it was issued -- a ds_read that re-used them right behind the store changed what lanes
@@ -281,10 +401,17 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       }
       buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {
-        if (FAST) {
+        if (FAST && C == 1) {
           acc[0] += hva; acc[0] += hvb;
           acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
           acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
+        } else if (FAST) {
+          acc[0] += hva; acc[0] += hvb;
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) {
+            acc[2 + ch] = __builtin_fma(Ika[ch], hva, acc[2 + ch]); acc[2 + ch] = __builtin_fma(Ikb[ch], hvb, acc[2 + ch]);
+          }
+          acc[2 + 2 * C] = __builtin_fma(uda, uda, acc[2 + 2 * C]); acc[2 + 2 * C] = __builtin_fma(udb, udb, acc[2 + 2 * C]);
         } else {
           acc[0] += hva; acc[1] += (1 - hva); acc[2] += Ia * hva; acc[3] += Ia * (1 - hva); acc[4] += uda * uda;
           acc[0] += hvb; acc[1] += (1 - hvb); acc[2] += Ib * hvb; acc[3] += Ib * (1 - hvb); acc[4] += udb * udb;
@@ -323,7 +450,12 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
 #pragma unroll
       for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64x2<POL>(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
       const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
-      const u32x4_t IQ = INTERIOR ? buf_load_b128(ri, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
+      u32x4_t IQ[NIQ];
+      if (C == 1) IQ[0] = INTERIOR ? buf_load_b128(ri, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
+      else {
+#pragma unroll
+        for (int j = 0; j < NIQ; ++j) IQ[j] = INTERIOR ? buf_load_b128(ri, q_voff[j], (unsigned)(ib + R) * (unsigned)w) : IMQ3(ib + R, j);
+      }
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         if (INTERIOR || (ib + k) < s1) row(ib + k, k, true);   // wave-uniform: rows past the strip end cost nothing
@@ -337,8 +469,17 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
             const double da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
             const double db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
             acc[0] += da; acc[0] += db;
-            acc[2] = __builtin_fma((double)(im[k] & 0xff), da, acc[2]);
-            acc[2] = __builtin_fma((double)((im[k] >> 8) & 0xff), db, acc[2]);
+            if (C == 1) {
+              acc[2] = __builtin_fma((double)(im[k] & 0xff), da, acc[2]);
+              acc[2] = __builtin_fma((double)((im[k] >> 8) & 0xff), db, acc[2]);
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < C; ++ch) {
+                const int s = samples(ch, k);
+                acc[2 + ch] = __builtin_fma((double)(s & 0xff), da, acc[2 + ch]);
+                acc[2 + ch] = __builtin_fma((double)(s >> 8), db, acc[2 + ch]);
+              }
+            }
           }
         }
       }
@@ -372,20 +513,21 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   }
   const double total = block_reduce<NS>(acc, sred);
   if (chain) {
-    chain_publish<1>(a, total);   // fixed-point atomics + the sum u_diff^2 row: nothing waits (chain_device.h)
+    chain_publish<C>(a, total);   // fixed-point atomics + the sum u_diff^2 row: nothing waits (chain_device.h)
   } else {
-    publish_partials_and_maybe_finalize<1>(a, total, sred, sfin, s_last, a.nparts);
+    publish_partials_and_maybe_finalize<C>(a, total, sred, sfin, s_last, a.nparts);
   }
   if (a.dbg_times && tid == 0) a.dbg_times[(size_t)a.nparts * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <bool FAST, int MINW, int POL>
+template <int C, bool FAST, int MINW, int POL, bool POLY = false>
 hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 {
-  using L = Wave2Smem<FAST>;
+  using L = Wave2Smem<FAST, C, !POLY>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup
-  hipLaunchKernelGGL((csv_wave2_kernel<FAST, MINW, POL>), dim3(a.nparts + extra), dim3(CVH_BLOCK), L::bytes, s, a);
+  CVH_LAUNCH((csv_wave2_kernel<C, FAST, MINW, POL, POLY>), a.nparts + extra, L::bytes, s, a, "csv_wave2_kernel<%d, %s, %d, %d, %s>", C,
+             CVH_TF(FAST), MINW, POL, CVH_TF(POLY));
   return hipGetLastError();
 }
 
@@ -393,11 +535,15 @@ hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 
 int cvh_wave2_cols() { return W2; }
 
-hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s)
+hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s)
 {
-  if (!fast) return launch_wave2<false, 2, 1>(a, s);
+  if (channels == 3) {   // FAST only (api.hip routes STRICT to kernel 2); use_lut = 0 selects the quadratic region term
+    if (a.use_lut) return a.wave_pol ? launch_wave2<3, true, 3, 1, false>(a, s) : launch_wave2<3, true, 3, 0, false>(a, s);
+    return a.wave_pol ? launch_wave2<3, true, 3, 1, true>(a, s) : launch_wave2<3, true, 3, 0, true>(a, s);
+  }
+  if (!fast) return launch_wave2<1, false, 2, 1>(a, s);
   // default: 3 waves/SIMD with branch-free rows (measured 65.1 vs 66.3 us for 4 waves/SIMD with the per-row branch)
-  if (a.wave_minw == 4) return launch_wave2<true, 4, 1>(a, s);
-  if (a.wave_pol == 2) return launch_wave2<true, 3, 2>(a, s);   // diagnostic: plain stores, non-temporal loads
-  return a.wave_pol ? launch_wave2<true, 3, 1>(a, s) : launch_wave2<true, 3, 0>(a, s);   // cache policy of the rows: wave2_device.h
+  if (a.wave_minw == 4) return launch_wave2<1, true, 4, 1>(a, s);
+  if (a.wave_pol == 2) return launch_wave2<1, true, 3, 2>(a, s);   // diagnostic: plain stores, non-temporal loads
+  return a.wave_pol ? launch_wave2<1, true, 3, 1>(a, s) : launch_wave2<1, true, 3, 0>(a, s);   // cache policy of the rows: wave2_device.h
 }

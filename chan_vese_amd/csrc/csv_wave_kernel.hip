@@ -502,13 +502,13 @@ hipError_t launch_wave_g(const CvhStepArgs &a, hipStream_t s)
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup of chain mode
   if constexpr (FAST && LUT && G == 1) {   // the shipped flavours exist with write-through stores too
     if (a.wave_pol == 1) {
-      if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G, 1>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
-      else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G, 1>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
+      if (imgv) CVH_LAUNCH((csv_wave_kernel<C, FAST, LUT, MINW, true, G, 1>), a.nparts + extra, lds, s, a, "csv_wave_kernel<%d, %s, %s, %d, true, %d, 1>", C, CVH_TF(FAST), CVH_TF(LUT), MINW, G);
+      else CVH_LAUNCH((csv_wave_kernel<C, FAST, LUT, MINW, false, G, 1>), a.nparts + extra, lds, s, a, "csv_wave_kernel<%d, %s, %s, %d, false, %d, 1>", C, CVH_TF(FAST), CVH_TF(LUT), MINW, G);
       return hipGetLastError();
     }
   }
-  if (imgv) hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, true, G>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
-  else hipLaunchKernelGGL((csv_wave_kernel<C, FAST, LUT, MINW, false, G>), dim3(a.nparts + extra), dim3(CVH_BLOCK), lds, s, a);
+  if (imgv) CVH_LAUNCH((csv_wave_kernel<C, FAST, LUT, MINW, true, G>), a.nparts + extra, lds, s, a, "csv_wave_kernel<%d, %s, %s, %d, true, %d, 0>", C, CVH_TF(FAST), CVH_TF(LUT), MINW, G);
+  else CVH_LAUNCH((csv_wave_kernel<C, FAST, LUT, MINW, false, G>), a.nparts + extra, lds, s, a, "csv_wave_kernel<%d, %s, %s, %d, false, %d, 0>", C, CVH_TF(FAST), CVH_TF(LUT), MINW, G);
   return hipGetLastError();
 }
 

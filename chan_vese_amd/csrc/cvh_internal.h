@@ -46,6 +46,11 @@ struct CvhChainAcc { long long v[CVH_CHAIN_SETS][64]; };
 //   [0] sum H(u)  [1] sum (1-H(u))  [2..2+C) sum I_k H  [2+C..2+2C) sum I_k (1-H)  [2+2C] sum u_diff^2
 __host__ __device__ constexpr int cvh_nsums(int C) { return 3 + 2 * C; }
 
+// What a launcher WOULD launch (cvh_launch_info, include/chanvese_hip.h): filled at the launch site itself, by the
+// same code path that selects the kernel flavour and the grid (CVH_LAUNCH below) -- nothing re-derives the choice.
+struct CvhLaunchNote { char name[112]; unsigned grid, block, lds; };
+void cvh_fill_note(CvhLaunchNote *note, unsigned grid, unsigned block, size_t lds, const char *fmt, ...);
+
 struct CvhStepArgs {
   const double *u_in;
   double *u_out;
@@ -96,7 +101,17 @@ struct CvhStepArgs {
   int wave_pol;                  // 2-pixel wave kernel: cache policy of the level-set rows (wave2_device.h): 1 write-through stores, 0 plain
   int wave_cls;                  // 2-pixel wave kernel: workgroups per XCD per dispatch round (= CUs per XCD); > 0 numbers the
                                  // workgroups class-major (round 0 of every XCD first), 0 = plain XCD-contiguous numbering
+  CvhLaunchNote *note;           // host only: non-null = describe the launch instead of issuing it (CVH_LAUNCH)
 };
+
+// The ONE way a step / Perona-Malik kernel is launched: KERNEL may be a parenthesised template-id; the trailing
+// arguments are a printf format + values that spell the instantiation as rocprofv3 prints it.
+#define CVH_LAUNCH(KERNEL, GRID, LDS, S, A, ...)                                                  \
+  do {                                                                                             \
+    if ((A).note) cvh_fill_note((A).note, (unsigned)(GRID), CVH_BLOCK, (size_t)(LDS), __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(CVH_BLOCK), (LDS), (S), (A));                 \
+  } while (0)
+#define CVH_TF(b) ((b) ? "true" : "false")
 
 #define CVH_ATAN_N 129
 #define CVH_ATAN2_N 257
@@ -112,6 +127,7 @@ struct CvhPmArgs {
   int fast;
   int strip_rows;    // wave kernel: rows per wave
   int pol;           // 2-step wave kernel: 1 = write-through stores (the state planes fit the Infinity Cache), 0 = plain
+  CvhLaunchNote *note;   // host only: describe the launch instead of issuing it (CVH_LAUNCH)
 };
 
 // ---- launchers (csv_kernels.hip / pm_kernels.hip / misc_kernels.hip) ----
@@ -121,7 +137,7 @@ int cvh_step_max_blocks(int h, int w);
 hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave2_cols();
-hipError_t cvh_launch_wave2(const CvhStepArgs &a, int fast, hipStream_t s);
+hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, int channels, hipStream_t s);
 hipError_t cvh_launch_wave(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave_cols();

@@ -298,8 +298,8 @@ hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hip
 hipError_t cvh_launch_pm_wave(const CvhPmArgs &a, hipStream_t s)
 {
   const int nbc = (a.tiles_x + 3) / 4, nstr = (a.h + a.strip_rows - 1) / a.strip_rows;
-  if (a.fast) hipLaunchKernelGGL(pm_wave_kernel<true>, dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
-  else hipLaunchKernelGGL(pm_wave_kernel<false>, dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  if (a.fast) CVH_LAUNCH(pm_wave_kernel<true>, nbc * nstr, 0, s, a, "pm_wave_kernel<true>");
+  else CVH_LAUNCH(pm_wave_kernel<false>, nbc * nstr, 0, s, a, "pm_wave_kernel<false>");
   return hipGetLastError();
 }
 
@@ -307,8 +307,8 @@ int cvh_pm_wave_cols() { return PWC; }
 
 hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s)
 {
-  if (a.fast) hipLaunchKernelGGL(pm_step_kernel<true>, dim3(a.tiles_x * a.tiles_y), dim3(CVH_BLOCK), 0, s, a);
-  else hipLaunchKernelGGL(pm_step_kernel<false>, dim3(a.tiles_x * a.tiles_y), dim3(CVH_BLOCK), 0, s, a);
+  if (a.fast) CVH_LAUNCH(pm_step_kernel<true>, a.tiles_x * a.tiles_y, 0, s, a, "pm_step_kernel<true>");
+  else CVH_LAUNCH(pm_step_kernel<false>, a.tiles_x * a.tiles_y, 0, s, a, "pm_step_kernel<false>");
   return hipGetLastError();
 }
 

@@ -186,7 +186,7 @@ hipError_t cvh_launch_pm_wave2(const CvhPmArgs &a, hipStream_t s)
 {
   const int nbc = (a.tiles_x + 1) / 2, nstr = (a.h + a.strip_rows - 1) / a.strip_rows;
   const int grid = nbc * ((nstr + 1) / 2);
-  if (a.fast) hipLaunchKernelGGL(pm_wave2_kernel<true>, dim3(grid), dim3(CVH_BLOCK), 0, s, a);
-  else hipLaunchKernelGGL(pm_wave2_kernel<false>, dim3(grid), dim3(CVH_BLOCK), 0, s, a);
+  if (a.fast) CVH_LAUNCH(pm_wave2_kernel<true>, grid, 0, s, a, "pm_wave2_kernel<true>");
+  else CVH_LAUNCH(pm_wave2_kernel<false>, grid, 0, s, a, "pm_wave2_kernel<false>");
   return hipGetLastError();
 }

@@ -192,9 +192,9 @@ int cvh_pm_wave_k2_cols() { return P2C; }
 hipError_t cvh_launch_pm_wave_k2(const CvhPmArgs &a, hipStream_t s)
 {
   const int nbc = (a.tiles_x + 3) / 4, nstr = (a.h + a.strip_rows - 1) / a.strip_rows;
-  if (a.fast && a.pol) hipLaunchKernelGGL((pm_wave_k2_kernel<true, 1>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
-  else if (a.fast) hipLaunchKernelGGL((pm_wave_k2_kernel<true, 0>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
-  else if (a.pol) hipLaunchKernelGGL((pm_wave_k2_kernel<false, 1>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
-  else hipLaunchKernelGGL((pm_wave_k2_kernel<false, 0>), dim3(nbc * nstr), dim3(CVH_BLOCK), 0, s, a);
+  if (a.fast && a.pol) CVH_LAUNCH((pm_wave_k2_kernel<true, 1>), nbc * nstr, 0, s, a, "pm_wave_k2_kernel<true, 1>");
+  else if (a.fast) CVH_LAUNCH((pm_wave_k2_kernel<true, 0>), nbc * nstr, 0, s, a, "pm_wave_k2_kernel<true, 0>");
+  else if (a.pol) CVH_LAUNCH((pm_wave_k2_kernel<false, 1>), nbc * nstr, 0, s, a, "pm_wave_k2_kernel<false, 1>");
+  else CVH_LAUNCH((pm_wave_k2_kernel<false, 0>), nbc * nstr, 0, s, a, "pm_wave_k2_kernel<false, 0>");
   return hipGetLastError();
 }

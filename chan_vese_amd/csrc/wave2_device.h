@@ -12,15 +12,18 @@ constexpr int R2 = 4;        // rows per group = ring slots
 constexpr int IMGP2 = 144;   // bytes per row of the per-wave image tile (9 x 16-byte pieces)
 constexpr int NS2 = cvh_nsums(1);
 
-template <bool FAST>
+// C channels: one image tile per channel; LUT = the region term as a 256-entry table per channel (LUT false: the
+// 3-channel flavour evaluates it as a quadratic in the sample, wave2 kernel POLY)
+template <bool FAST, int C = 1, bool LUT = true>
 struct Wave2Smem {
-  static constexpr int wave_doubles = R2 * XP2 + 64 + R2 * IMGP2 / 8;     // ring + scratch + image tile
+  static constexpr int NS = cvh_nsums(C);
+  static constexpr int wave_doubles = R2 * XP2 + 64 + C * R2 * IMGP2 / 8; // ring + scratch + image tiles
   static constexpr int off_x = 0;
   static constexpr int off_red = off_x + 4 * wave_doubles;                // 4*NS
-  static constexpr int off_fin = off_red + 4 * NS2;                       // NS (+1 pad)
-  static constexpr int off_atan = off_fin + NS2 + 1;                      // FAST: CVH_ATAN2_N
-  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // FAST: 256 x {term, I}
-  static constexpr int off_flag = off_lut + (FAST ? 512 : 0);
+  static constexpr int off_fin = off_red + 4 * NS + (4 * NS) % 2;         // NS (+1 pad)
+  static constexpr int off_atan = off_fin + NS + NS % 2;                  // FAST: CVH_ATAN2_N
+  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // FAST && LUT: C x 256 x {term, I}
+  static constexpr int off_flag = off_lut + (FAST && LUT ? C * 512 : 0);
   static constexpr int doubles = off_flag + 2;
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };

@@ -146,7 +146,7 @@ int cvh_run(cvh_context *ctx, int max_steps, int *steps_done, double *last_norm)
  * later wait for them.  `stopped` reports whether the stop rule fired. */
 int cvh_enqueue_steps(cvh_context *ctx, int nsteps);
 /* Optional: does the one-off host work of an upcoming cvh_enqueue_steps(ctx, nsteps) now (strip table,
- * capture + instantiation of the 16-step hipGraph of the current ping-pong parity), so that a caller
+ * capture + instantiation of the 16-step hipGraph of the position the chunk starts at), so that a caller
  * timing the enqueue/sync pair with its own clock does not see it.  cvh_run and cvh_enqueue_steps do the
  * same work themselves before they open cvh_last_run_ms's interval. */
 int cvh_warm(cvh_context *ctx, int nsteps);
@@ -187,6 +187,13 @@ int cvh_pm_trip_count(double L, double T);
  * last cvh_perona_malik. */
 int cvh_last_run_ms(cvh_context *ctx, float *ms);
 int cvh_last_pm_ms(cvh_context *ctx, float *ms);
+/* Which kernel the library launches, as "key=value" text written by the launch sites themselves (no counterpart in
+ * the reference: the kernel is an implementation detail; bench.py names it in its roofline object and profiles/ are
+ * matched against it).  phase 0: the CSV step as the next cvh_run / cvh_enqueue_steps launches it with the current
+ * options -- kernel=<instantiation as rocprofv3 prints it> grid= block= lds_bytes= strips= strip_rows= chain= wave_pol=
+ * math= steps_per_graph=; phase 1: what the last cvh_perona_malik launched (CVH_ERR_STATE before the first).
+ * Launches nothing.  Truncates to cap - 1 characters. */
+int cvh_launch_info(cvh_context *ctx, int phase, char *buf, int cap);
 
 /* ParallelPixelFunction::operator()(cv::Range(start,end)) with a tagged function,
  * src/ParallelPixelFunction.cpp:12-17 — host buffer form: data is a w-wide CV_64FC1

@@ -219,21 +219,70 @@ double cvo_stop_condition(const uint8_t *const *channels, int nof_channels, int 
   return r;
 }
 
-double cvo_csv_step(const uint8_t *const *channels, int nof_channels, int h, int w,
-                    const cvo_params *p, double *u, double *c1, double *c2)
+/* ---- exact-sum adjudicator (test infrastructure beside the restatement, not part of it) ------------------
+ * The region means of src/main.cpp:272-280 with the SAME per-pixel terms the reference adds -- hv = H_eps(u)
+ * for the inside, fl(1 - H_eps(u)) for the outside, fl(I * hv) -- but added without accumulation error:
+ * Neumaier-compensated long double sums per row, the rows combined the same way (so the result does not depend
+ * on the thread count).  The reference's own sequential double sums of 16.7 M terms carry ~1e-12 relative
+ * rounding error at 4096^2; this variant says which of two trajectories that differ by that much is the
+ * accurate one (tests/test_exact_sums.py, tests/test_gpu_fullsize.py). */
+typedef struct { long double s, c; } cvo_acc;
+
+static void acc_add(cvo_acc *a, long double x)
+{
+  const long double t = a->s + x;
+  if (fabsl(a->s) >= fabsl(x)) a->c += (a->s - t) + x;
+  else a->c += (x - t) + a->s;
+  a->s = t;
+}
+
+void cvo_region_sums_exact(const uint8_t *img, const double *u, int h, int w, double eps,
+                           long double out[4])
+{
+  cvo_acc *rows = (cvo_acc *)calloc((size_t)h * 4, sizeof(cvo_acc));
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < h; ++i) {
+    cvo_acc a[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int j = 0; j < w; ++j) {
+      const double hv = cvo_regularized_heaviside(u[(size_t)i * w + j], eps); /* :193 */
+      const double ho = 1 - hv;                                               /* :267 */
+      const double pix = img[(size_t)i * w + j];
+      acc_add(&a[0], hv);
+      acc_add(&a[1], pix * hv);                                               /* :276, product rounded to double */
+      acc_add(&a[2], ho);
+      acc_add(&a[3], pix * ho);
+    }
+    for (int s = 0; s < 4; ++s) rows[(size_t)i * 4 + s] = a[s];
+  }
+  for (int s = 0; s < 4; ++s) {
+    cvo_acc t = {0, 0};
+    for (int i = 0; i < h; ++i) { acc_add(&t, rows[(size_t)i * 4 + s].s); acc_add(&t, rows[(size_t)i * 4 + s].c); }
+    out[s] = t.s + t.c;
+  }
+  free(rows);
+}
+
+void cvo_region_means_exact(const uint8_t *img, const double *u, int h, int w, double eps,
+                            double *c1, double *c2)
+{
+  long double s[4];
+  cvo_region_sums_exact(img, u, h, w, eps, s);
+  *c1 = (double)(s[1] / s[0]); /* nom / denom, :280 */
+  *c2 = (double)(s[3] / s[2]);
+}
+
+/* src/main.cpp:977-994 given the region means of this iteration */
+static double csv_step_given_means(const uint8_t *const *channels, int nof_channels, int h, int w,
+                                   const cvo_params *p, double *u, const double *c1, const double *c2)
 {
   const size_t n = (size_t)h * w;
-  cvo_closure hs = {heaviside_thunk, p->eps, NULL};
   double *u_diff = (double *)calloc(n, sizeof(double)); /* :965 */
   double *vin = (double *)malloc(n * sizeof(double));
   double *vout = (double *)malloc(n * sizeof(double));
   double *kappa = (double *)malloc(n * sizeof(double));
   double *u_cp = (double *)malloc(n * sizeof(double));
 
-  /* channel loop :968-980, serial in k (the race-free meaning) */
   for (int k = 0; k < nof_channels; ++k) {
-    c1[k] = region_variance_fn(channels[k], u, h, w, CVO_INSIDE, &hs);  /* :973 */
-    c2[k] = region_variance_fn(channels[k], u, h, w, CVO_OUTSIDE, &hs); /* :974 */
     cvo_variance_penalty(channels[k], h, w, c1[k], p->lambda1[k], vin);  /* :977 */
     cvo_variance_penalty(channels[k], h, w, c2[k], p->lambda2[k], vout); /* :978 */
     for (size_t q = 0; q < n; ++q) u_diff[q] += vout[q] - vin[q];        /* :979 */
@@ -266,6 +315,26 @@ double cvo_csv_step(const uint8_t *const *channels, int nof_channels, int h, int
 
   free(u_diff); free(vin); free(vout); free(kappa); free(u_cp);
   return nrm;
+}
+
+double cvo_csv_step(const uint8_t *const *channels, int nof_channels, int h, int w,
+                    const cvo_params *p, double *u, double *c1, double *c2)
+{
+  cvo_closure hs = {heaviside_thunk, p->eps, NULL};
+  /* channel loop :968-980, serial in k (the race-free meaning); the two serial sweeps per channel come first here,
+   * the penalties (which only need c1[k], c2[k]) follow in csv_step_given_means in the same k order */
+  for (int k = 0; k < nof_channels; ++k) {
+    c1[k] = region_variance_fn(channels[k], u, h, w, CVO_INSIDE, &hs);  /* :973 */
+    c2[k] = region_variance_fn(channels[k], u, h, w, CVO_OUTSIDE, &hs); /* :974 */
+  }
+  return csv_step_given_means(channels, nof_channels, h, w, p, u, c1, c2);
+}
+
+double cvo_csv_step_exact(const uint8_t *const *channels, int nof_channels, int h, int w,
+                          const cvo_params *p, double *u, double *c1, double *c2)
+{
+  for (int k = 0; k < nof_channels; ++k) cvo_region_means_exact(channels[k], u, h, w, p->eps, &c1[k], &c2[k]);
+  return csv_step_given_means(channels, nof_channels, h, w, p, u, c1, c2);
 }
 
 int cvo_csv_run(const uint8_t *const *channels, int nof_channels, int h, int w,

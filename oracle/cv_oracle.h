@@ -61,6 +61,16 @@ double cvo_stop_condition(const uint8_t *const *channels, int nof_channels, int 
  * u_diff_norm; c1/c2 (length nof_channels) receive the region means used. */
 double cvo_csv_step(const uint8_t *const *channels, int nof_channels, int h, int w,
                     const cvo_params *p, double *u, double *c1, double *c2);
+/* Exact-sum adjudicator (beside the restatement, not part of it): the region means of :272-280 from the same
+ * per-pixel terms, added with Neumaier-compensated long double sums (accumulation error ~1e-19 instead of the
+ * ~1e-12 of 16.7 M sequential double additions).  out = {sum H, sum fl(I H), sum fl(1-H), sum fl(I fl(1-H))}. */
+void cvo_region_sums_exact(const uint8_t *img, const double *u, int h, int w, double eps,
+                           long double out[4]);
+void cvo_region_means_exact(const uint8_t *img, const double *u, int h, int w, double eps,
+                            double *c1, double *c2);
+/* cvo_csv_step with the region means taken from cvo_region_means_exact (everything else identical). */
+double cvo_csv_step_exact(const uint8_t *const *channels, int nof_channels, int h, int w,
+                          const cvo_params *p, double *u, double *c1, double *c2);
 /* src/main.cpp:950-1001. trace (may be NULL) receives per iteration
  * [c1_0..c1_{C-1}, c2_0..c2_{C-1}, norm] for at most trace_cap iterations.
  * Returns the number of iterations executed (t at break, or max_steps). */

@@ -63,6 +63,9 @@ def lib():
         L.cvo_stop_condition.argtypes = [u8pp, C.c_int, C.c_int, C.c_int, C.c_double]
         L.cvo_csv_step.restype = C.c_double
         L.cvo_csv_step.argtypes = [u8pp, C.c_int, C.c_int, C.c_int, C.POINTER(Params), dp, dp, dp]
+        L.cvo_csv_step_exact.restype = C.c_double
+        L.cvo_csv_step_exact.argtypes = L.cvo_csv_step.argtypes
+        L.cvo_region_means_exact.argtypes = [u8p, dp, C.c_int, C.c_int, C.c_double, dp, dp]
         L.cvo_csv_run.restype = C.c_int
         L.cvo_csv_run.argtypes = [u8pp, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
                                   dp, dp, dp, C.c_int]
@@ -156,6 +159,38 @@ def csv_step(planes, u, params):
     c2 = np.zeros(3)
     nrm = lib().cvo_csv_step(arr, len(planes), h, w, C.byref(params), _dp(u), _dp(c1), _dp(c2))
     return nrm, c1[:len(planes)].copy(), c2[:len(planes)].copy()
+
+
+def csv_step_exact(planes, u, params):
+    """csv_step with the region means from compensated long double sums (the exact-sum adjudicator)."""
+    planes, arr = _planes(planes)
+    h, w = planes[0].shape
+    assert u.dtype == np.float64 and u.flags.c_contiguous
+    c1 = np.zeros(3)
+    c2 = np.zeros(3)
+    nrm = lib().cvo_csv_step_exact(arr, len(planes), h, w, C.byref(params), _dp(u), _dp(c1), _dp(c2))
+    return nrm, c1[:len(planes)].copy(), c2[:len(planes)].copy()
+
+
+def region_means_exact(planes, u, eps=1.0):
+    """(c1[C], c2[C]) of the level set u: the reference's per-pixel terms (src/main.cpp:272-280) added without
+    accumulation error (Neumaier-compensated long double)."""
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    h, w = u.shape
+    c1, c2 = [], []
+    for pl in planes:
+        pl = np.ascontiguousarray(pl, dtype=np.uint8)
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        lib().cvo_region_means_exact(_u8p(pl), _dp(u), h, w, float(eps), C.byref(a), C.byref(b))
+        c1.append(a.value)
+        c2.append(b.value)
+    return np.array(c1), np.array(c2)
+
+
+def region_means(planes, u, eps=1.0):
+    """(c1[C], c2[C]) as the reference computes them: sequential double sums, one sweep per mean."""
+    return (np.array([region_mean(pl, u, 0, eps) for pl in planes]),
+            np.array([region_mean(pl, u, 1, eps) for pl in planes]))
 
 
 def csv_run(planes, u0, params, max_steps, trace=True):

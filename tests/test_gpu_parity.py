@@ -85,6 +85,59 @@ def test_csv_two_pixel_kernel_edge_shapes(capi, oracle, shape, mode, math):
         assert np.array_equal(m_g, oracle.mask(u_c))
 
 
+@pytest.mark.parametrize("lut", [1, 0])
+@pytest.mark.parametrize("shape", [(1, 144), (2, 160), (3, 256), (5, 2016), (9, 272), (40, 144), (17, 1008), (8, 4096), (150, 528)])
+def test_csv_three_channel_two_pixel_kernel(capi, oracle, shape, lut):
+    """Round 3: the 2-pixel wave kernel with three channels (csv_wave2_kernel<3, ...>, FAST only, "kernel" = 3): one image
+    tile per channel, samples read inside the row, region term from three tables (lut = 1) or as the quadratic
+    sum_k (qa_k I + qb_k) I + qc with wave-uniform coefficients (lut = 0).  Same shapes as the 1-channel edge-shape test,
+    per-channel lambdas, nu != 0, ragged strips."""
+    h, w = shape
+    rng = np.random.default_rng(7 * h + w)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]
+    u0 = oracle.checkerboard(h, w) if min(h, w) > 2 else rng.normal(size=shape)
+    pk = dict(tol=0, lambda1=[1, 0.8, 0.5], lambda2=[0.7, 0.5, 1], nu=0.01)
+    for steps, opts in ((1, {}), (7, dict(strip_rows=8)), (4, dict(chain=0)), (19, {})):
+        u_c, _, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
+        with capi.Context(h, w, 3, capi.make_params(**pk)) as ctx:
+            ctx.set_option("kernel", 3)
+            ctx.set_option("lut", lut)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            assert ctx.launch_info()["kernel"].startswith("csv_wave2_kernel<3, true, 3, "), ctx.launch_info()
+            assert ctx.launch_info()["kernel"].endswith("true>" if lut == 0 else "false>")
+            ctx.set_option("trace", steps)
+            ctx.set_image(planes)
+            ctx.set_levelset(u0)
+            done, nrm = ctx.run(steps)
+            u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(steps), ctx.get_mask()
+        assert done == steps
+        assert rel_err(u_g, u_c) <= 1e-9, (steps, opts, rel_err(u_g, u_c))
+        assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0)
+        assert np.array_equal(m_g, oracle.mask(u_c))
+
+
+def test_launch_info_names_what_runs(capi):
+    """cvh_launch_info is written by the launch sites themselves: the kernel instantiation as rocprofv3 prints it."""
+    with capi.Context(512, 1024, 1) as ctx:
+        ctx.set_image([synth.disk(1024, h=512, w=1024)])
+        ctx.init_checkerboard()
+        i = ctx.launch_info()
+        assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1, false>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"
+        ctx.set_option("kernel", 2)
+        assert ctx.launch_info()["kernel"].startswith("csv_wave_kernel<1, true, true, 5, true, 1, 1>")
+        ctx.set_option("math_mode", 1)
+        assert ctx.launch_info()["kernel"].startswith("csv_wave_kernel<1, false, false, 3,") and ctx.launch_info()["math"] == "strict"
+        ctx.set_option("kernel", 0)
+        assert ctx.launch_info()["kernel"].startswith("csv_step_kernel<1, 14, false, false,")
+        with pytest.raises(capi.CvhError):
+            ctx.launch_info(1)            # no Perona-Malik run yet
+        ctx.perona_malik(30.0, 0.25, 2.25)
+        p = ctx.launch_info(1)
+        assert p["kernel"].startswith("pm_wave_k2_kernel<false,") and p["steps_per_launch"] == "2" and p["trips"] == "9"
+        assert p["last_step_kernel"].startswith("pm_wave_kernel<false>")
+
+
 @pytest.mark.parametrize("mode,math", MODES)
 @pytest.mark.parametrize("opts", [dict(kernel=0, tile_rows=14), dict(kernel=0, tile_rows=16, lut=0),
                                   dict(kernel=0, tile_rows=14, dma=1),
@@ -271,6 +324,80 @@ def test_chain_mode_stop_edges(capi, oracle, shape, channels, kernel):
         u1 = u0.copy()
         oracle.csv_step(planes, u1, oracle.make_params(tol=0, **lam))
         assert rel_err(ctx.get_levelset(), u1) <= 1e-12
+
+
+@pytest.mark.parametrize("shape,channels,kernel", [((64, 160), 1, 3), ((48, 100), 3, 2)])
+def test_graph_chunks_that_are_not_multiples_of_four(capi, oracle, shape, channels, kernel):
+    """The captured step arguments have period 4 in chain mode (the sum set of the first step): chunk sizes >= 16 that are
+    not multiples of 4 -- sync_every 18 and 50, cvh_enqueue_steps(18) repeated without a sync, a run that follows a run of
+    odd length -- cycle through the four cached graphs (api.hip, ensure_step_graph).  Results equal the oracle's and the
+    plain-launch path's bit for bit."""
+    h, w = shape
+    rng = np.random.default_rng(11 * h + w + channels)
+    planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(channels)]
+    u0 = oracle.checkerboard(h, w)
+    lam = dict(lambda1=[1, 0.8, 0.5], lambda2=[0.7, 0.5, 1]) if channels == 3 else {}
+    pk = dict(tol=0, **lam)
+    steps = 118
+    u_c, _, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
+
+    def gpu(drive, graph=1):
+        with capi.Context(h, w, channels, capi.make_params(**pk)) as ctx:
+            ctx.set_option("kernel", kernel)
+            ctx.set_option("graph", graph)
+            ctx.set_option("trace", steps)
+            ctx.set_image(planes)
+            ctx.set_levelset(u0)
+            done = drive(ctx)
+            assert done == steps
+            return ctx.get_levelset(), ctx.get_trace(steps)
+
+    def by_sync_every(n):
+        def drive(ctx):
+            ctx.set_option("sync_every", n)
+            return ctx.run(steps)[0]
+        return drive
+
+    def by_enqueue_18(ctx):
+        for _ in range(6):
+            ctx.enqueue_steps(18)          # 2 plain launches + one graph of 16, starting at a new phase every time
+        ctx.enqueue_steps(10)
+        return ctx.sync()[0]
+
+    def by_odd_runs(ctx):                  # every run ends on a count that is not a multiple of 4: the next starts at another phase
+        total = 0
+        for n in (17, 19, 33, 18, 31):
+            total += ctx.run(n)[0]
+        return total
+
+    ref_u, ref_tr = gpu(by_sync_every(32), graph=0)
+    assert rel_err(ref_u, u_c) <= 1e-6 and np.allclose(ref_tr[:10], tr_c[:10], rtol=1e-9, atol=0)
+    for drive in (by_sync_every(18), by_sync_every(50), by_enqueue_18):
+        u_g, tr_g = gpu(drive)
+        assert np.array_equal(u_g, ref_u) and np.array_equal(tr_g, ref_tr)
+    u_g, _ = gpu(by_odd_runs)              # the trace restarts with every run: compare the level set
+    assert np.array_equal(u_g, ref_u)
+
+
+def test_warm_does_not_touch_the_chain_state(capi, oracle):
+    """cvh_warm only captures: it must not mark chain-mode launches as pending.  chain=0 run (means valid in the state block),
+    chain=1 + warm(16), back to chain=0: the next launches must still use the right region means (a flush
+    kernel used to overwrite them from sum sets that were never seeded)."""
+    h, w = 64, 160
+    img = synth.disk(64, 200, 50, noise=10, seed=4, h=h, w=w)
+    u0 = oracle.checkerboard(h, w)
+    u_c, _, _, _ = oracle.csv_run([img], u0, oracle.make_params(tol=0), 9)
+    with capi.Context(h, w, 1, capi.make_params(tol=0)) as ctx:
+        ctx.set_option("kernel", 3)
+        ctx.set_option("chain", 0)
+        ctx.set_image([img])
+        ctx.set_levelset(u0)
+        assert ctx.run(4)[0] == 4
+        ctx.set_option("chain", 1)
+        ctx.warm(16)
+        ctx.set_option("chain", 0)
+        assert ctx.run(5)[0] == 5
+        assert rel_err(ctx.get_levelset(), u_c) <= 1e-9
 
 
 def test_unlimited_steps_runs_to_stop(capi, oracle):
