@@ -389,7 +389,7 @@ def test_kernel_flavours_agree_at_4096(capi):
 
 def test_two_pixel_kernel_beyond_the_cache_policy_switch(capi):
     """4608^2: the footprint (361 MB) is above the 300 MB switch, so the 2-pixel kernel runs its plain-store flavour
-    (csv_wave2_kernel<true, 3, 0>) by default -- compared with the 1-pixel kernel, GPU vs GPU, 3 iterations
+    (csv_wave2_kernel<1, true, 3, 0, false>) by default -- compared with the 1-pixel kernel, GPU vs GPU, 3 iterations
     (the store-data hazard only showed under memory back-pressure, and every flavour has its own register allocation)."""
     n = 4608
     planes = [synth.disk(n)]
@@ -407,7 +407,7 @@ def test_two_pixel_kernel_beyond_the_cache_policy_switch(capi):
 
     ref, _ = run(dict(kernel=2))
     got, info = run({})
-    assert info["kernel"] == "csv_wave2_kernel<true, 3, 0>", info
+    assert info["kernel"] == "csv_wave2_kernel<1, true, 3, 0, false>", info
     assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
 
 
