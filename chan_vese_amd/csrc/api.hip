@@ -67,6 +67,7 @@ struct cvh_context {
   int *h_status = nullptr;  // pinned + mapped: {steps_done, stopped} written by the device
   unsigned long long *d_isums = nullptr, *h_isums = nullptr;   // image_sums_kernel: {sum p, sum p^2} per plane (device / pinned)
   int strip_rows = 0;   // 0 auto
+  int strips = 0;       // 2-pixel kernel: exact number of strips (0 auto); rows are dealt by cumulative weight, so any count works
   int num_cus = 256;
   double *d_atan = nullptr;
   unsigned long long *d_dbg = nullptr;  // diagnostic stamps (option "debug_times")
@@ -355,6 +356,9 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
   } else if (!strcmp(key, "strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "strip_rows must be >= 0");
     c->strip_rows = (int)value;
+  } else if (!strcmp(key, "strips")) {
+    if (value < 0 || value > c->h) return fail(c, CVH_ERR_ARG, "strips must be 0 (auto) .. h");
+    c->strips = (int)value;
   } else if (!strcmp(key, "lut")) {
     c->use_lut = value != 0;
   } else if (!strcmp(key, "dma")) {
@@ -568,19 +572,29 @@ static Geometry resolve_geometry(const cvh_context *c)
     g.rows = 4;
     g.tiles_x = (c->w + cvh_wave2_cols() - 1) / cvh_wave2_cols();
     const int nbc = (g.tiles_x + 1) / 2;
-    int sr = c->strip_rows;
+    int sr = c->strip_rows, small_exact = 0;
     if (sr <= 0) {
       const int occ = use_fast(c) ? (c->wave_minw == 4 ? 4 : 3) : 2;   // as compiled: cvh_launch_wave2
       int nstrips = 2 * ((c->num_cus * occ) / nbc);
       // small planes (a full round would mean strips of < 13 rows: 3 halo rows and a pipeline fill each): ~1.8 workgroups
       // per CU instead -- measured at 2048^2: 16 rows 23.2, 18 rows 24.1, 20 rows 21.4, 22 rows 22.7, 24 rows 22.8 us
-      if (nstrips > 160) { nstrips = 2 * (int)(c->num_cus * 1.8 / nbc + 0.5); if (nstrips < 2) nstrips = 2; }
+      // (round 3, exact strip counts at 2048^2, one context: 56 strips 22.8 us, 84 21.2, 100 21.1, 104 20.8, 108 21.2, 112 20.7, 114 22.1 --
+      // one workgroup more than two per CU --, 128 21.4, 140 21.1, 168 21.6: flat from 84 to 168 except just above a multiple of the CU
+      // count; TWO workgroups per CU, never more)
+      bool exact = false;
+      if (nstrips > 160) { nstrips = 2 * ((2 * c->num_cus) / nbc); if (nstrips < 2) nstrips = 2; exact = true; }
       if (nstrips < 1) nstrips = 1;
       sr = (c->h + nstrips - 1) / nstrips;
-      if (sr < 8) sr = 8;
+      if (sr < 8) { sr = 8; exact = false; }
+      if (exact && c->wave_cls && c->wave_xcd) small_exact = nstrips;   // the class-major table deals rows by weight: any count works
     }
     g.strip_rows = sr;
-    g.tiles_y = (c->h + sr - 1) / sr;
+    g.tiles_y = small_exact ? small_exact : (c->h + sr - 1) / sr;
+    if (c->strips > 0 && c->strip_rows <= 0 && c->wave_cls && c->wave_xcd) {   // exact count ("strips"): the class-major table deals rows by weight
+      g.tiles_y = c->strips;
+      g.strip_rows = (c->h + c->strips - 1) / c->strips;
+      if (g.strip_rows < 8) { g.strip_rows = 8; g.tiles_y = (c->h + 7) / 8; }
+    }
     g.nblocks = nbc * ((g.tiles_y + 1) / 2);
     return g;
   }

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    d[3] = (unsigned long long)xcc | ((unsigned long long)hwid << 8);   // d[2] = time the first group started
+    d[3] = (unsigned long long)xcc | ((unsigned long long)hwid << 8) | ((unsigned long long)(unsigned)bid << 40);   // d[2] = time the first group started; bid = the workgroup's logical index
   }
   const double total = block_reduce<NS>(acc, sred);
   if (chain) {

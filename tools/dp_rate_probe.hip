@@ -7,8 +7,8 @@
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
-enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_RCP64, OP_RSQ64, OP_FMA32, OP_MOV32, OP_CNDMASK, OP_CVT, OP_LDEXP, OP_RNDNE, OP_MIN64, OP_CND_SGPR, OP_CMP_CND, OP_CMP64, OP_READLANE, OP_DPP, OP_BFI, OP_XOR, NOPS };
-static const char *names[NOPS] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_rsq_f64", "v_fma_f32", "v_mov_b32", "v_cndmask", "v_cvt_f64_u32", "v_ldexp_f64", "v_rndne_f64", "v_min_f64", "v_cndmask(sgpr mask)", "v_cmp+v_cndmask", "v_cmp_gt_f64", "v_readlane", "v_mov_dpp", "v_bfi_b32", "v_xor_b32"};
+enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_RCP64, OP_RSQ64, OP_FMA32, OP_MOV32, OP_CNDMASK, OP_CVT, OP_LDEXP, OP_RNDNE, OP_MIN64, OP_CND_SGPR, OP_CMP_CND, OP_CMP64, OP_READLANE, OP_DPP, OP_BFI, OP_XOR, OP_RCP32, OP_RSQ32, OP_CVT32_64, OP_CVT64_32, OP_MOV64, NOPS };
+static const char *names[NOPS] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_rsq_f64", "v_fma_f32", "v_mov_b32", "v_cndmask", "v_cvt_f64_u32", "v_ldexp_f64", "v_rndne_f64", "v_min_f64", "v_cndmask(sgpr mask)", "v_cmp+v_cndmask", "v_cmp_gt_f64", "v_readlane", "v_mov_dpp", "v_bfi_b32", "v_xor_b32", "v_rcp_f32", "v_rsq_f32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_mov_b64"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void probe(double *out, unsigned long long *ticks, int iters, double a, double b)
@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256) void probe(double *out, unsigned long long *ti
       if (OP == OP_DPP) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(n[k]) : "v"(n[(k + 1) & 7]));
       if (OP == OP_BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(n[k]) : "v"(n[(k + 1) & 7]), "v"(n[(k + 2) & 7]));
       if (OP == OP_XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[k]) : "v"(n[(k + 1) & 7]));
+      if (OP == OP_RCP32) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[k]));
+      if (OP == OP_RSQ32) asm volatile("v_rsq_f32 %0, %0" : "+v"(f[k]));
+      if (OP == OP_CVT32_64) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[k]) : "v"(x[k]));
+      if (OP == OP_CVT64_32) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x[k]) : "v"(f[k]));
+      if (OP == OP_MOV64) asm volatile("v_mov_b64 %0, %1" : "=v"(x[k]) : "v"(x[(k + 1) & 7]));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -112,6 +117,11 @@ int main()
     run<OP_LDEXP>(bpc, cus, iters, d_out, d_ticks);
     run<OP_RNDNE>(bpc, cus, iters, d_out, d_ticks);
     run<OP_MIN64>(bpc, cus, iters, d_out, d_ticks);
+    run<OP_RCP32>(bpc, cus, iters, d_out, d_ticks);
+    run<OP_RSQ32>(bpc, cus, iters, d_out, d_ticks);
+    run<OP_CVT32_64>(bpc, cus, iters, d_out, d_ticks);
+    run<OP_CVT64_32>(bpc, cus, iters, d_out, d_ticks);
+    run<OP_MOV64>(bpc, cus, iters, d_out, d_ticks);
   }
   return 0;
 }

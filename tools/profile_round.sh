@@ -8,12 +8,15 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 bench.py $ARGS --steps 200 --warmup 10 --no-cpu-baseline --no-phases"
-# 1. un-profiled bench line
-( cd $R && timeout -k 10 300 $CMD > $out/bench_default.json 2> $out/bench_default.err ) || echo "bench failed"
+# the config's own command: its iteration count after 100 warm-up iterations, result check, cpu_baseline and phases included (round 3:
+# the lines of EVERY config carry cpu_baseline); the kernel trace below profiles the same command
+CMD="python3 bench.py $ARGS"
+# 1. un-profiled bench line (+ the driver's short command for the headline config)
+( cd $R && timeout -k 10 600 $CMD > $out/bench_default.json 2> $out/bench_default.err ) || echo "bench failed"
+[ -z "$ARGS" ] && ( cd $R && timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err )
 # 2. kernel trace + stats
 rm -rf /tmp/kt
-( cd $R && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- $CMD > /tmp/kt.log 2>&1 ) || { echo "kernel-trace failed"; tail -5 /tmp/kt.log; }
+( cd $R && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- $CMD > /tmp/kt.log 2>&1 ) || { echo "kernel-trace failed"; tail -5 /tmp/kt.log; }
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv
 # 3. PMC passes
 python3 - > $out/pmc_summary.json <<'PY'
@@ -43,7 +46,8 @@ python3 - $out <<'PY'
 import json, sys, csv
 o = sys.argv[1]
 b = json.loads(open(o + "/bench_default.json").read())
-print("bench avg launch us", b["roofline"]["avg_launch_us"], "frac", b["roofline"]["frac"])
+print("bench avg launch us", b["roofline"]["avg_launch_us"], "frac", b["roofline"]["frac"], "frac_wall", b["roofline"].get("frac_wall"), "kernel", b["roofline"]["kernel"],
+      "checked", b.get("checked"), "cpu_baseline", (b.get("cpu_baseline") or {}).get("value"), "pm", (b.get("pm") or {}).get("us_per_step"))
 try:
     for r in csv.DictReader(open(o + "/kernel_stats.csv")):
         print("kernel_stats:", r["Name"][:90], "calls", r["Calls"], "avg ns", r["AverageNs"])
