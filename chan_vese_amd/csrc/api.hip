@@ -57,6 +57,13 @@ struct cvh_context {
   int chain_pb = 0;             // sum set that belongs to the level set at run-counter 0
   bool chain_pending = false;   // chain launches enqueued since the last flush
   bool chain_acc_valid = false; // the fixed-point sets hold the sums of the current level set
+  // resident kernel (csv_resident_kernel.hip): cache-resident planes iterate in LDS, one cooperative launch per chunk
+  CvhResident *d_resident = nullptr;
+  double *d_res_halo = nullptr;
+  int *h_resident = nullptr;     // pinned: {arrive, error} of the last launch
+  int resident_opt = 0;          // option "resident": 0 off, 1 on where it applies
+  int resident_cap = -1;         // workgroups the device holds at once (-1: not asked yet, 0: unavailable)
+  bool resident_used = false;    // a resident launch since the last sync: its error word is checked there
   int far_terms = 5;            // terms of the far-field series of H_eps (5: valid from 32 eps, 4: from 64 eps)
   int wave_pol = -1;            // option "wave_pol": cache policy of the 2-pixel kernel's rows (-1 auto by footprint, 0 plain, 1 write-through)
   int wave_cls = 1;             // 2-pixel wave kernel: class-major workgroup numbering (dispatch rounds)
@@ -170,6 +177,9 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->pm_graph) (void)hipGraphExecDestroy(c->pm_graph);
   if (c->d_dummy) (void)hipFree(c->d_dummy);
   if (c->d_chain) (void)hipFree(c->d_chain);
+  if (c->d_resident) (void)hipFree(c->d_resident);
+  if (c->d_res_halo) (void)hipFree(c->d_res_halo);
+  if (c->h_resident) (void)hipHostFree(c->h_resident);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->h_status) (void)hipHostFree(c->h_status);
   if (c->d_isums) (void)hipFree(c->d_isums);
@@ -329,6 +339,9 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     c->wave_skew = (int)value;
   } else if (!strcmp(key, "chain")) {
     c->chain_opt = value != 0;
+  } else if (!strcmp(key, "resident")) {
+    if (value != 0 && value != 1) return fail(c, CVH_ERR_ARG, "resident must be 0 or 1");
+    c->resident_opt = (int)value;
   } else if (!strcmp(key, "far_terms")) {
     if (value != 4 && value != 5) return fail(c, CVH_ERR_ARG, "far_terms must be 4 or 5");
     c->far_terms = (int)value;
@@ -649,6 +662,33 @@ static bool use_chain(const cvh_context *c, const Geometry &g)
   return (g.strip == 3 || g.strip == 2) && use_fast(c) && c->finalize_mode == 0 && c->chain_opt;
 }
 
+// Resident mode (csv_resident_kernel.hip): the plane is cut into tr x tc tiles of <= 128 x 128 pixels, one workgroup per tile, all
+// co-resident (one per CU), the level set stays in LDS for a chunk of iterations.  Applies to 1 channel, FAST arithmetic, chain-mode
+// sums, even widths, and planes that fit: tiles <= what the device holds, every tile 16 .. 128 rows.
+struct ResidentGeom { int tr, tc; };
+static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
+{
+  if (!c->resident_opt || c->C != 1 || !use_fast(c) || !c->chain_opt || c->finalize_mode != 0 || (c->w & 1) || c->w < 16 || c->h < 16) return false;
+  if (!(c->kernel == -1 || c->kernel == 2 || c->kernel == 3)) return false;
+  if (c->resident_cap < 0) {
+    int coop = 0;
+    c->resident_cap = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && coop)
+      c->resident_cap = cvh_resident_blocks_per_cu() * c->num_cus;
+  }
+  if (c->resident_cap <= 0) return false;
+  const int tw = cvh_resident_tile_w(), thmax = cvh_resident_tile_hmax();
+  const int tc = (c->w + tw - 1) / tw;
+  int cap = c->resident_cap < CVH_RESIDENT_MAX_TILES ? c->resident_cap : CVH_RESIDENT_MAX_TILES;
+  if (cap > c->num_cus) cap = c->num_cus;                      // one workgroup per CU: a second one on a CU would wait for its slot
+  int tr = cap / tc;
+  if (tr < 1) return false;
+  if (tr > c->h / 16) tr = c->h / 16;                          // tiles of >= 16 rows (every wave's band >= 2 rows)
+  if ((c->h + tr - 1) / tr > thmax) return false;              // does not fit the LDS of the CUs
+  rg->tr = tr; rg->tc = tc;
+  return true;
+}
+
 // `step` = index of the launch inside the run (c->enqueued when it is enqueued): selects the chain-mode sum set
 static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step)
 {
@@ -921,6 +961,7 @@ static int ensure_step_graph(cvh_context *c, int parity)
 // cvh_last_run_ms nor a caller's wall clock around cvh_enqueue_steps / cvh_sync is charged with it.
 static int warm_impl(cvh_context *c, long nsteps)
 {
+  { ResidentGeom rg; if (resident_geometry(c, &rg)) return CVH_OK; }   // one cooperative launch per chunk: nothing to capture
   const Geometry g = resolve_geometry(c);
   if (g.strip >= 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
   if (c->use_graph && nsteps >= kGraphSteps) {
@@ -935,9 +976,46 @@ static int warm_impl(cvh_context *c, long nsteps)
   return CVH_OK;
 }
 
+// One cooperative launch per chunk of iterations (csv_resident_kernel.hip).
+static int launch_resident(cvh_context *c, const ResidentGeom &rg, int nsteps, CvhLaunchNote *note)
+{
+  const int ntiles = rg.tr * rg.tc;
+  if (!note) {
+    if (!c->d_resident) {
+      HIPCHK(c, hipMalloc((void **)&c->d_resident, sizeof(CvhResident)));
+      HIPCHK(c, hipMalloc((void **)&c->d_res_halo, (size_t)2 * CVH_RESIDENT_MAX_TILES * cvh_resident_halo_doubles() * sizeof(double)));
+      HIPCHK(c, hipHostMalloc((void **)&c->h_resident, 64, hipHostMallocDefault));
+      memset(c->h_resident, 0, 64);
+    }
+  }
+  constexpr int kMaxPerLaunch = 4096;
+  for (int s = 0; s < nsteps || note;) {
+    const int n = nsteps - s < kMaxPerLaunch ? nsteps - s : kMaxPerLaunch;
+    CvhStepArgs a;
+    fill_args(c, &a, (c->cur_base + c->enqueued) & 1, c->enqueued);
+    if (!a.chain) return fail(c, CVH_ERR_STATE, "resident mode needs chain-mode sums");
+    a.tiles_x = rg.tc; a.tiles_y = rg.tr; a.nparts = ntiles;
+    a.resident = c->d_resident;
+    a.res_halo = c->d_res_halo;
+    a.res_steps = n;
+    a.res_poll_cap = 2000000;      // seconds of polling before a wait gives up (the grid always drains)
+    a.note = note;
+    if (note) { HIPCHK(c, cvh_launch_resident(a, c->stream)); return CVH_OK; }
+    HIPCHK(c, hipMemsetAsync(c->d_resident, 0, 64 + (size_t)ntiles * 64, c->stream));
+    HIPCHK(c, cvh_launch_resident(a, c->stream));
+    c->chain_pending = true;       // the flush kernel writes c1 / c2 of the final level set into the state block at the next sync
+    c->resident_used = true;
+    c->enqueued += n;
+    s += n;
+  }
+  return CVH_OK;
+}
+
 static int enqueue_impl(cvh_context *c, int nsteps)
 {
   {
+    ResidentGeom rg;
+    if (resident_geometry(c, &rg)) return launch_resident(c, rg, nsteps, nullptr);
     const Geometry g = resolve_geometry(c);
     if (g.strip >= 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
   }
@@ -1003,7 +1081,16 @@ static int sync_impl(cvh_context *c)
   if (rc != CVH_OK) return rc;
   if (c->timing_open) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   if (!via_flush) HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
+  if (c->resident_used) HIPCHK(c, hipMemcpyAsync(c->h_resident, c->d_resident, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->resident_used) {
+    c->resident_used = false;
+    if (c->h_resident[1]) {
+      c->timing_open = false;
+      return fail(c, CVH_ERR_HIP, "the resident step kernel gave up waiting for a workgroup (%d arrivals): the level set of this run is invalid",
+                  c->h_resident[0]);
+    }
+  }
   if (via_flush) {
     c->h_state[0].steps_done = c->h_status[0];
     c->h_state[0].stopped = c->h_status[1];
@@ -1369,6 +1456,16 @@ extern "C" int cvh_launch_info(cvh_context *c, int phase, char *buf, int cap)
   }
   // the CSV step as the next cvh_run / cvh_enqueue_steps would launch it: the launcher itself describes it (CVH_LAUNCH)
   CvhLaunchNote note{};
+  {
+    ResidentGeom rg;
+    if (resident_geometry(c, &rg)) {
+      const int rc = launch_resident(c, rg, 1, &note);
+      if (rc != CVH_OK) return rc;
+      snprintf(buf, (size_t)cap, "kernel=%s grid=%u block=%u lds_bytes=%u data_flow=4 tiles_y=%d tiles_x=%d tile_rows=%d chain=1 math=fast "
+               "steps_per_launch=chunk", note.name, note.grid, note.block, note.lds, rg.tr, rg.tc, (c->h + rg.tr - 1) / rg.tr);
+      return CVH_OK;
+    }
+  }
   const int rc = launch_one_step(c, current_buffer(c), c->enqueued, true, &note);
   if (rc != CVH_OK) return rc;
   const Geometry g = resolve_geometry(c);
@@ -1377,6 +1474,20 @@ extern "C" int cvh_launch_info(cvh_context *c, int phase, char *buf, int cap)
   snprintf(buf, (size_t)cap, "kernel=%s grid=%u block=%u lds_bytes=%u data_flow=%d wave_columns=%d strips=%d strip_rows=%d chain=%d "
            "wave_pol=%d math=%s steps_per_graph=%d", note.name, note.grid, note.block, note.lds, g.strip, g.tiles_x, g.tiles_y,
            g.strip_rows, a.chain ? 1 : 0, a.wave_pol, use_fast(c) ? "fast" : "strict", c->use_graph ? kGraphSteps : 0);
+  return CVH_OK;
+}
+
+// Diagnostic (not part of include/chanvese_hip.h): the synchronisation words of the last resident launch: {arrive, error, go[0 .. n)}.
+extern "C" int cvh_debug_resident_read(cvh_context *c, unsigned *out, int ngo)
+{
+  if (!c || !out || ngo < 0 || ngo > CVH_RESIDENT_MAX_TILES) return CVH_ERR_ARG;
+  if (!c->d_resident) return fail(c, CVH_ERR_STATE, "no resident launch yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<unsigned> tmp(16 + (size_t)ngo * 16);
+  HIPCHK(c, hipMemcpy(tmp.data(), c->d_resident, tmp.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+  out[0] = tmp[0]; out[1] = tmp[1];
+  for (int i = 0; i < ngo; ++i) out[2 + i] = tmp[16 + (size_t)i * 16];
   return CVH_OK;
 }
 

@@ -1,0 +1,419 @@
+// csv_resident_kernel.hip — cache-resident planes (gfx950, wave64, 1 channel, FAST arithmetic, chain-mode sums): the level set
+// lives in LDS for a whole chunk of iterations.
+//
+// A 2048^2 level set is 32 MiB; the 256 CUs of an MI355X hold 40 MiB of LDS.  One cooperative launch cuts the plane into
+// tiles_y x tiles_x tiles of <= 128 rows x 128 columns, ONE workgroup (8 waves) per tile and per CU, loads every tile into its
+// CU's LDS once, runs `res_steps` iterations of src/main.cpp:963-1001 on it in place, and writes the tiles back at the end.
+// What a launch per iteration pays every iteration -- the launch gap, the dispatch ramp, 7 rows of loads per 21-row strip before
+// the first row computes, the drain of the last waves, every level-set byte through the memory system twice -- is paid once per
+// chunk; what crosses workgroups per iteration is
+//   * the tile's border rows / columns (the 7-point cross reaches 2 up / left, 1 down / right: 6 x 128 doubles per tile), through a
+//     double-buffered global halo buffer, written and read with sc1 (agent scope);
+//   * the fixed-point sums of chain mode (chain_device.h) and one sum u_diff^2 row per workgroup;
+//   * ONE grid barrier: an arrival counter; the last workgroup to arrive books the iteration (norm, stop rule src/main.cpp:1000,
+//     trace row), clears the sum set after next and writes one "go" word per workgroup (every workgroup polls its own word: same-address
+//     polling does not scale, tools/experiments/persist/README.md).  The stop rule therefore fires at the reference's iteration
+//     with no extra iteration computed.
+// Every wait is a bounded poll: a workgroup that gives up raises CvhResident::error and leaves, and so does everybody waiting
+// for it -- the grid always drains; the host reports the error at the next synchronisation.
+//
+// Inside a tile: wave v owns a band of rows and all 128 columns (lane l <-> columns 2l, 2l + 1), marches down its band with
+// u(i-1), u(i) in registers and u(i+1) and the x-neighbours read from the LDS tile one row ahead, and writes row i IN PLACE once it
+// is computed.  Bands only meet at their first / last rows: every wave reads the two rows above its band and the row below it
+// into registers before any wave writes (one workgroup barrier).  Column -1's normalised x-gradient, which lane 0 needs for
+// kappa_x of column 0 and no lane owns, is computed for all rows of the tile by one thread per row before the march.
+// The arithmetic of a pixel is csv_wave2_kernel.hip's FAST flavour operation by operation.
+#include "csv_device.h"
+#include "buffer_ops.h"
+#include "wave_math.h"
+#include "chain_device.h"
+
+using namespace cvh_dev;
+
+namespace {
+
+constexpr int RT_W = 128;                 // tile width: 64 lanes x 2 pixels
+constexpr int RT_HMAX = 128;              // most rows a tile may have (LDS)
+constexpr int RT_PITCH = 132;             // doubles per LDS row: tile columns -2 .. 129
+constexpr int RT_THREADS = 512, RT_WAVES = 8;
+constexpr int RT_HALO = 6 * RT_W;         // doubles a tile publishes per iteration: bottom 2 rows, top row, right 2 columns, left column
+constexpr int kWordStride = 16;           // one synchronisation word per 64 bytes
+constexpr unsigned kAbort = 0xffffffffu;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+struct ResSmem {
+  static constexpr int NS = cvh_nsums(1);
+  static constexpr int off_u = 0;                                           // (RT_HMAX + 3) rows x RT_PITCH: tile rows -2 .. TH
+  static constexpr int off_img = off_u + (RT_HMAX + 3) * RT_PITCH;          // RT_HMAX x 128 bytes
+  static constexpr int off_lut = off_img + RT_HMAX * RT_W / 8;              // 256 x {term, I}
+  static constexpr int off_atan = off_lut + 512;                            // CVH_ATAN2_N (+1 pad)
+  static constexpr int off_nxl = off_atan + CVH_ATAN2_N + 1;                // RT_HMAX: normalised x-gradient of column -1
+  static constexpr int off_red = off_nxl + RT_HMAX;                         // RT_WAVES x NS
+  static constexpr int off_flag = off_red + RT_WAVES * NS;
+  static constexpr int doubles = off_flag + 2;
+  static constexpr size_t bytes = (size_t)doubles * sizeof(double);
+};
+static_assert(ResSmem::bytes <= 160 * 1024, "the tile, its halo ring and the tables must fit one CU's LDS");
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Sum over the workgroup's 8 waves in a fixed order; every thread returns the total of sum `s` it asked for (s < NS).
+template <int NS>
+__device__ __forceinline__ void block_reduce8(double (&acc)[NS], double *sred /*[8*NS]*/, double (&total)[NS])
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double v[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) v[s] = wave_sum(acc[s]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sred[wave * NS + s] = v[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    double t = sred[s];
+#pragma unroll
+    for (int wv = 1; wv < RT_WAVES; ++wv) t += sred[wv * NS + s];
+    total[s] = t;
+  }
+  __syncthreads();
+}
+
+// Thread 0 polls this workgroup's "go" word until it reaches iteration `it` (bounded); the workgroup meets at a barrier.
+// Returns the word (bit 0: leave), or kAbort.
+__device__ __forceinline__ unsigned wg_wait_go(const unsigned *p, int it, const CvhStepArgs &a, int *s_flag)
+{
+  if (threadIdx.x == 0) {
+    unsigned v = kAbort;
+    int ok = 0;
+    for (int i = 0; i < a.res_poll_cap; ++i) {
+      v = ld_agent(p);
+      if (v == kAbort) break;
+      if ((v >> 1) >= (unsigned)it) { ok = 1; break; }
+      if (ld_agent((const unsigned *)&a.resident->error) != 0u) break;
+      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(4);
+    }
+    if (!ok) { st_agent(&a.resident->error, 1); v = kAbort; }
+    *s_flag = (int)v;
+  }
+  __syncthreads();
+  const unsigned v = (unsigned)*s_flag;
+  __syncthreads();
+  return v;
+}
+
+__global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhStepArgs a)
+{
+  using L = ResSmem;
+  constexpr int NS = L::NS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *su = smem + L::off_u;
+  unsigned char *simg = reinterpret_cast<unsigned char *>(smem + L::off_img);
+  double *slut = smem + L::off_lut;
+  double *satan = smem + L::off_atan;
+  double *snxl = smem + L::off_nxl;
+  double *sred = smem + L::off_red;
+  int *s_flag = (int *)(smem + L::off_flag);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = a.h, w = a.w;
+  CvhResident *const rs = a.resident;
+  if (*(const_int_p)&a.st->stopped != 0) return;    // sticky flag of an EARLIER launch: the same for every workgroup
+  const int t_first = *(const_int_p)&a.st->steps_done;   // iterations booked before this launch (written before it began)
+
+  // ---- this workgroup's tile
+  const int tr = a.tiles_y, tc = a.tiles_x, ntiles = tr * tc;
+  const int bid = (int)blockIdx.x;
+  const int ty = bid / tc, tx = bid % tc;
+  const int r0 = (int)(((long)h * ty) / tr), r1 = (int)(((long)h * (ty + 1)) / tr);
+  const int TH = r1 - r0;                              // <= RT_HMAX (host)
+  const int c0 = tx * RT_W;
+  const int TWv = (w - c0) < RT_W ? (w - c0) : RT_W;   // even (host: w even)
+  // LDS address of tile element (row r in -2 .. TH, column c in -2 .. 129)
+  auto S = [&](int r, int c) -> double * { return su + (r + 2) * RT_PITCH + (c + 2); };
+
+  // ---- once per launch: tables, image tile, level-set tile with its halo ring straight from the plane (clamped = BORDER_REPLICATE)
+  for (int q = tid; q < CVH_ATAN2_N; q += RT_THREADS) satan[q] = a.atan2_tab[q];
+  if ((w & 15) == 0) {                                                   // rows are 16-byte aligned and the tile's width is a multiple of 16
+    for (int q = tid; q < TH * (RT_W / 16); q += RT_THREADS) {           // 16-byte pieces of the image tile
+      const int r = q / (RT_W / 16), p = q % (RT_W / 16);
+      const int col = c0 + 16 * p < w ? c0 + 16 * p : w - 16;            // pieces beyond the image: no lane reads them
+      const uint4 v = *reinterpret_cast<const uint4 *>(a.img[0] + (size_t)(r0 + r) * w + col);
+      *reinterpret_cast<uint4 *>(simg + r * RT_W + 16 * p) = v;
+    }
+  } else {
+    for (int q = tid; q < TH * RT_W; q += RT_THREADS) {                  // other widths: byte by byte (once per launch)
+      const int r = q / RT_W, c = q % RT_W;
+      simg[q] = a.img[0][(size_t)(r0 + r) * w + clampi(c0 + c, 0, w - 1)];
+    }
+  }
+  for (int q = tid; q < (TH + 3) * RT_PITCH; q += RT_THREADS) {
+    const int r = q / RT_PITCH - 2, c = q % RT_PITCH - 2;
+    const int gr = clampi(r0 + r, 0, h - 1), gc = clampi(c0 + c, 0, w - 1);
+    su[q] = a.u_in[(size_t)gr * w + gc];
+  }
+  __syncthreads();
+
+  const double l1 = a.lambda1[0], l2 = a.lambda2[0];
+  const double eps = a.eps, eps2 = eps * eps;
+  const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_k[4], a.far_thr};
+  // this wave's band of tile rows
+  const int rb0 = (TH * wave) / RT_WAVES, rb1 = (TH * (wave + 1)) / RT_WAVES;
+  const int ca = 2 * lane;                                  // tile column of pixel a
+  const bool lane_valid = ca < TWv;
+  const double vmask = lane_valid ? 1.0 : 0.0;
+  const double fxa = (c0 + ca <= 0) ? 0.0 : 1.0;            // kappa_x(i, 0) = 0 (src/main.cpp:371)
+  double *const halo_mine[2] = {a.res_halo + (size_t)bid * RT_HALO, a.res_halo + ((size_t)ntiles + bid) * RT_HALO};
+  auto norm = [&](double fwd, double bwd, double c) -> double { return normalised4(fwd, bwd, c + c); };
+
+  int executed = 0;
+  const int nit = a.res_steps;
+  for (int it = 0; it < nit; ++it) {
+    const int phase = (a.chain_phase + it) & 3;
+    // ---- the grid barrier behind iteration it - 1, then its halos (iteration 0 loaded them with the tile)
+    if (it > 0) {
+      const unsigned go = wg_wait_go(&rs->go[(size_t)bid * kWordStride], it, a, s_flag);
+      if (go == kAbort || (go & 1u)) break;
+      const double *const hb = a.res_halo + (size_t)((it - 1) & 1) * ntiles * RT_HALO;
+      // top halo rows -2, -1 <- the tile above's bottom two rows; bottom halo row TH <- the tile below's top row;
+      // left halo columns -2, -1 <- the left tile's right two columns; right halo column TWv <- the right tile's left column;
+      // at the image's border: BORDER_REPLICATE from the tile's own edge (src/main.cpp:351-354)
+      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
+        const int piece = q / RT_W, k = q % RT_W;
+        double v;
+        double *dst;
+        if (piece < 2) {            // top rows
+          dst = S(piece - 2, k);
+          v = ty > 0 ? ld_agent_f64(hb + (size_t)(bid - tc) * RT_HALO + piece * RT_W + k) : *S(0, k);
+        } else if (piece == 2) {    // bottom row
+          dst = S(TH, k);
+          v = ty < tr - 1 ? ld_agent_f64(hb + (size_t)(bid + tc) * RT_HALO + 2 * RT_W + k) : *S(TH - 1, k);
+        } else if (piece < 5) {     // left columns
+          dst = S(k < TH ? k : 0, piece - 5);
+          v = tx > 0 ? ld_agent_f64(hb + (size_t)(bid - 1) * RT_HALO + piece * RT_W + k) : *S(k < TH ? k : 0, 0);
+          if (k >= TH) dst = nullptr;
+        } else {                    // right column
+          dst = S(k < TH ? k : 0, TWv);
+          v = tx < tc - 1 ? ld_agent_f64(hb + (size_t)(bid + 1) * RT_HALO + 5 * RT_W + k) : *S(k < TH ? k : 0, TWv - 1);
+          if (k >= TH) dst = nullptr;
+        }
+        if (dst) *dst = v;
+      }
+    }
+    // ---- region means of u(it) from the fixed-point sums, table of the variance term (:307-310, :979, :985)
+    double c1, c2;
+    {
+      const long long entry = __hip_atomic_load(&a.chain->v[phase][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double m1[1], m2[1];
+      chain_means<1>(a, entry, m1, m2);
+      c1 = m1[0]; c2 = m2[0];
+      if (tid < 256) {
+        const double v = (double)tid;
+        const double d1 = v - c1, d2 = v - c2;
+        const double reg = (d2 * d2) * l2 - (d1 * d1) * l1;
+        slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
+        slut[2 * tid + 1] = v;
+      }
+    }
+    __syncthreads();
+    // ---- normalised x-gradient of tile column -1, one thread per row (nobody owns that column; lane 0 needs it for column 0)
+    if (tid < TH) snxl[tid] = norm(*S(tid, 0), *S(tid, -2), *S(tid, -1));
+    // ---- every wave takes the rows around its band into registers before any wave writes
+    const double2_t um2_0 = *reinterpret_cast<const double2_t *>(S(rb0 - 2, ca));
+    double2_t um = *reinterpret_cast<const double2_t *>(S(rb0 - 1, ca));
+    double2_t u0 = *reinterpret_cast<const double2_t *>(S(rb0, ca));
+    const double2_t ubot = *reinterpret_cast<const double2_t *>(S(rb1, ca));
+    double uw = *S(rb0, ca - 1), ue = *S(rb0, ca + 2);
+    const double2_t u1st = *reinterpret_cast<const double2_t *>(S(rb0 + 1 < rb1 ? rb0 + 1 : rb0, ca));   // row rb0 + 1 (own band, if it has one)
+    __syncthreads();
+
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0;
+    if (rb1 > rb0) {
+      double nypa = norm(u0.x, um2_0.x, um.x), nypb = norm(u0.y, um2_0.y, um.y);   // ny at row rb0 - 1
+      if (r0 + rb0 == 0) {   // kappa_y(0, .) = 0 (:372): ny_prev := row 0's own ny, the very expression the row uses
+        const double2_t up0 = (rb0 + 1 < rb1) ? u1st : ubot;
+        nypa = norm(up0.x, um.x, u0.x); nypb = norm(up0.y, um.y, u0.y);
+      }
+      for (int i = rb0; i < rb1; ++i) {
+        const bool lastrow = i + 1 >= rb1;                      // wave-uniform
+        double2_t up;
+        double uw_n = 0.0, ue_n = 0.0;
+        if (lastrow) up = ubot;
+        else {
+          up = *reinterpret_cast<const double2_t *>(S(i + 1, ca));
+          uw_n = *S(i + 1, ca - 1); ue_n = *S(i + 1, ca + 2);
+        }
+        const int smp = (int)*reinterpret_cast<const unsigned short *>(simg + i * RT_W + ca);
+        const int ba = smp & 0xff, bb = smp >> 8;
+        const double nxl0 = snxl[i];
+        // x-gradients first: nx(b) is the west gradient of lane + 1's a (DPP), nx(a) the west gradient of b
+        const double nxa = norm(u0.y, uw, u0.x);
+        const double nxb = norm(ue, u0.x, u0.y);
+        const double nxla_d = dpp_from_left(nxb);
+        const double nxla = lane == 0 ? nxl0 : nxla_d;
+        auto pixel = [&](double c, double n_, double s_, double nx, double nxl, double fx, double &nyp, int byte, double &ud_out,
+                         double &Ik_out) -> double {
+          const double ny = norm(s_, n_, c);
+          const double kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
+          const double2_t e = reinterpret_cast<const double2_t *>(slut)[byte];
+          double ud = __builtin_fma(kappa, a.alpha, e.x);                  // :985
+          const double qd = __builtin_fma(c, c, eps2) * a.dk1;             // 1 / delta_eps(u)
+          const double q0 = __builtin_amdgcn_rcp(qd);
+          const double er = __builtin_fma(-qd, q0, 1.0);
+          ud = ud * __builtin_fma(__builtin_fma(er, er, er), q0, q0);      // :992
+          nyp = ny;
+          ud_out = ud; Ik_out = e.y;
+          return c + ud;                                                   // :994
+        };
+        double uda, udb, Ia, Ib;
+        const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nypa, ba, uda, Ia);
+        const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nypb, bb, udb, Ib);
+        double hva, hvb;
+        if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {   // far / near decided per wave
+          hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
+        } else {
+          hva = heaviside_centred_near(va, a.inv_eps, satan); hvb = heaviside_centred_near(vb, a.inv_eps, satan);
+        }
+        if (lane_valid) *reinterpret_cast<double2_t *>(S(i, ca)) = double2_t{va, vb};   // in place: every reader of the old row i has it in registers
+        acc[0] += hva; acc[0] += hvb;
+        acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
+        acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
+        um = u0; u0 = up; uw = uw_n; ue = ue_n;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;   // exact: lanes beyond the image contribute nothing
+    }
+    double total[NS];
+    block_reduce8<NS>(acc, sred, total);    // (its barriers also order the tile writes before the border reads below)
+    executed = it + 1;
+
+    // ---- publish: fixed-point sums for the next iteration's means, the sum u_diff^2 row, the tile's border for the neighbours
+    {
+      long long *const set = &a.chain->v[(phase + 1) & 3][0];
+      const int shard = bid % chain_shards<1>();
+      if (tid == 0)
+        __hip_atomic_fetch_add(&set[shard], __double2ll_rn(total[0] * a.chain_scale[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 64)
+        __hip_atomic_fetch_add(&set[chain_shards<1>() + shard], __double2ll_rn(total[2] * a.chain_scale[1]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 128) st_agent_f64(&a.chain_s4[(size_t)(phase & 1) * ntiles + bid], total[4]);
+    }
+    {
+      double *const hb = halo_mine[it & 1];
+      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
+        const int piece = q / RT_W, k = q % RT_W;
+        double v;
+        if (piece < 2) v = *S(TH - 2 + piece, k);                    // bottom two rows   (TH >= 2: host)
+        else if (piece == 2) v = *S(0, k);                           // top row
+        else if (piece < 5) v = *S(k < TH ? k : 0, TWv - 5 + piece);  // right two columns: TWv - 2, TWv - 1
+        else v = *S(k < TH ? k : 0, 0);                              // left column
+        st_agent_f64(hb + q, v);
+      }
+    }
+    // ---- arrive; the last workgroup to arrive books the iteration and releases everybody
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&rs->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_flag = (old + 1u == (unsigned)(it + 1) * (unsigned)ntiles) ? 1 : 0;
+    }
+    __syncthreads();
+    const int last = *s_flag;
+    __syncthreads();
+    if (last) {
+      // iteration `it` is complete everywhere: norm (fixed order), trace row, stop rule (src/main.cpp:993-1000)
+      double nacc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) nacc[s] = 0;
+      const double *rows = a.chain_s4 + (size_t)(phase & 1) * ntiles;
+      for (int b = tid; b < ntiles; b += RT_THREADS) nacc[0] += ld_agent_f64(&rows[b]);
+      double ntot[NS];
+      block_reduce8<NS>(nacc, sred, ntot);
+      if (tid < 64) __hip_atomic_store(&a.chain->v[(phase + 2) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the set iteration it + 1 adds into
+      int stop_now = 0;
+      if (tid == 0) {
+        CvhState *st = a.st;
+        const int t = t_first + it;                      // (not read back: another XCD's L2 may hold a stale copy)
+        const double nrm = sqrt(ntot[0]);
+        // state words and trace rows are written by whichever workgroup arrives last -- a different XCD from one iteration to the
+        // next: write-through (agent-scope) stores, or two XCDs' L2s would race to write the same word back at the end of the kernel
+        if (a.trace && t < a.trace_cap) {
+          st_agent_f64(&a.trace[(size_t)t * 3], c1); st_agent_f64(&a.trace[(size_t)t * 3 + 1], c2); st_agent_f64(&a.trace[(size_t)t * 3 + 2], nrm);
+        }
+        st_agent_f64(&st->norm, nrm);
+        st_agent(&st->steps_done, t + 1);
+        st_agent(&st->pending, 0);
+        stop_now = nrm <= a.stop_cond;                  // :1000, after the update
+        if (stop_now) st_agent(&st->stopped, 1);
+        if (a.host_status) {
+          __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        *s_flag = stop_now;
+      }
+      __syncthreads();
+      stop_now = *s_flag;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned val = ((unsigned)(it + 1) << 1) | ((stop_now || it + 1 >= nit) ? 1u : 0u);
+      for (int i = tid; i < ntiles; i += RT_THREADS) st_agent(&rs->go[(size_t)i * kWordStride], val);
+    }
+  }
+  // ---- leave: every workgroup waits for the release behind the last iteration it computed (the bookkeeping of that iteration
+  // is then complete), then writes its tile back into the ping-pong buffer the per-launch path would hold the result in
+  if (executed > 0) {
+    const unsigned go = wg_wait_go(&rs->go[(size_t)bid * kWordStride], executed, a, s_flag);
+    if (go == kAbort) return;
+  }
+  // (an even count lands in the buffer the launch read from: every workgroup has long finished reading it -- the first grid
+  // barrier lies behind all the tile loads)
+  double *const dst = (executed & 1) ? a.u_out : const_cast<double *>(a.u_in);
+  if (executed > 0) {
+    for (int q = tid; q < TH * (RT_W / 2); q += RT_THREADS) {
+      const int r = q / (RT_W / 2), c = 2 * (q % (RT_W / 2));
+      if (c < TWv) *reinterpret_cast<double2_t *>(dst + (size_t)(r0 + r) * w + c0 + c) = *reinterpret_cast<const double2_t *>(S(r, c));
+    }
+  }
+}
+
+}  // namespace
+
+size_t cvh_resident_lds_bytes() { return ResSmem::bytes; }
+int cvh_resident_tile_w() { return RT_W; }
+int cvh_resident_tile_hmax() { return RT_HMAX; }
+int cvh_resident_halo_doubles() { return RT_HALO; }
+
+// Workgroups of the resident kernel one CU holds (0: not launchable, e.g. the LDS request was refused).
+int cvh_resident_blocks_per_cu()
+{
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  int n = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(csv_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ResSmem::bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached = 0;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, csv_resident_kernel, RT_THREADS, ResSmem::bytes) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  return cached = n;
+}
+
+hipError_t cvh_launch_resident(const CvhStepArgs &a, hipStream_t s)
+{
+  if (a.note) {
+    cvh_fill_note(a.note, (unsigned)(a.tiles_x * a.tiles_y), RT_THREADS, ResSmem::bytes, "csv_resident_kernel");
+    return hipSuccess;
+  }
+  CvhStepArgs copy = a;
+  void *params[] = {&copy};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(csv_resident_kernel), dim3(a.tiles_x * a.tiles_y), dim3(RT_THREADS), params,
+                                    (unsigned)ResSmem::bytes, s);
+}

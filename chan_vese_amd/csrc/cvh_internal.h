@@ -42,6 +42,15 @@ struct CvhState {
 constexpr int CVH_CHAIN_SETS = 4;
 struct CvhChainAcc { long long v[CVH_CHAIN_SETS][64]; };
 
+// Resident kernel (csv_resident_kernel.hip): the words its workgroups synchronise on, zeroed before every launch.
+constexpr int CVH_RESIDENT_MAX_TILES = 1024;
+struct CvhResident {
+  unsigned arrive;      // workgroups that finished an iteration, cumulative over the launch (iteration e complete: (e + 1) * tiles)
+  int error;            // a bounded wait gave up (a workgroup was not resident, or a fault): the launch drains, the host reports it
+  unsigned pad[14];
+  unsigned go[CVH_RESIDENT_MAX_TILES * 16];   // per workgroup, one word per 64 bytes: (iterations complete) << 1 | leave
+};
+
 // Sums carried per workgroup and reduced in a fixed order (deterministic):
 //   [0] sum H(u)  [1] sum (1-H(u))  [2..2+C) sum I_k H  [2+C..2+2C) sum I_k (1-H)  [2+2C] sum u_diff^2
 __host__ __device__ constexpr int cvh_nsums(int C) { return 3 + 2 * C; }
@@ -102,6 +111,10 @@ struct CvhStepArgs {
   int wave_cls;                  // 2-pixel wave kernel: workgroups per XCD per dispatch round (= CUs per XCD); > 0 numbers the
                                  // workgroups class-major (round 0 of every XCD first), 0 = plain XCD-contiguous numbering
   CvhLaunchNote *note;           // host only: non-null = describe the launch instead of issuing it (CVH_LAUNCH)
+  // resident kernel (csv_resident_kernel.hip): tiles_x x tiles_y tiles, one workgroup each
+  CvhResident *resident;         // synchronisation words
+  double *res_halo;              // [2][tiles][6 * 128] border rows / columns of every tile, by iteration parity
+  int res_steps, res_poll_cap;   // iterations in this launch; polls before a wait gives up
 };
 
 // The ONE way a step / Perona-Malik kernel is launched: KERNEL may be a parenthesised template-id; the trailing
@@ -139,6 +152,12 @@ hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStr
 int cvh_wave2_cols();
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, int channels, hipStream_t s);
+size_t cvh_resident_lds_bytes();
+int cvh_resident_tile_w();
+int cvh_resident_tile_hmax();
+int cvh_resident_halo_doubles();
+int cvh_resident_blocks_per_cu();
+hipError_t cvh_launch_resident(const CvhStepArgs &a, hipStream_t s);   // cooperative launch, a.res_steps iterations in LDS
 hipError_t cvh_launch_wave(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave_cols();
 hipError_t cvh_launch_init_sums(const CvhStepArgs &a, int channels, int fast, int *nparts_out,

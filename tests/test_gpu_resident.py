@@ -1,0 +1,136 @@
+"""Resident mode (csv_resident_kernel.hip, option "resident" = 1): cache-resident planes iterate in LDS, one cooperative launch
+per chunk of iterations, one workgroup per tile, a grid barrier per iteration.  Same parity bar as every other data flow:
+level set, c1 / c2 / norm of every iteration <= 1e-9 against the oracle over the first iterations, identical stop iteration,
+mask equal; plus what is specific to this flow: tiles with ragged edges, planes of one tile, chunk boundaries (a chunk writes
+the tiles back and the next one reloads them), continuation in the per-launch flow and back."""
+import numpy as np
+import pytest
+
+from chan_vese_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from chan_vese_amd import capi as m
+    m.lib()
+    assert m.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return m
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def resident_ctx(capi, h, w, pk):
+    ctx = capi.Context(h, w, 1, capi.make_params(**pk))
+    ctx.set_option("resident", 1)
+    info = ctx.launch_info()
+    assert info["kernel"] == "csv_resident_kernel", info     # the shape qualifies: otherwise the test would silently test another kernel
+    return ctx, info
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (16, 128), (32, 256), (48, 130), (96, 160), (128, 128), (130, 258), (200, 384), (256, 1024), (666, 500)])
+def test_resident_small_shapes(capi, oracle, shape):
+    h, w = shape
+    rng = np.random.default_rng(3 * h + w)
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    u0 = oracle.checkerboard(h, w)
+    pk = dict(tol=0, nu=0.01, dt=0.5)
+    for steps in (1, 2, 9):
+        u_c, _, nrm_c, tr_c = oracle.csv_run([img], u0, oracle.make_params(**pk), steps)
+        ctx, info = resident_ctx(capi, h, w, pk)
+        with ctx:
+            ctx.set_option("trace", steps)
+            ctx.set_image([img])
+            ctx.set_levelset(u0)
+            done, nrm = ctx.run(steps)
+            u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(steps), ctx.get_mask()
+            c1g, c2g = ctx.get_means()
+        assert done == steps, (shape, steps, done, info)
+        assert rel_err(u_g, u_c) <= 1e-9, (shape, steps, rel_err(u_g, u_c), info)
+        assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0), (shape, steps)
+        assert nrm == pytest.approx(nrm_c, rel=1e-9)
+        assert np.array_equal(m_g, oracle.mask(u_c))
+        assert c1g[0] == pytest.approx(oracle.region_mean(img, u_c, 0), rel=1e-9)
+        assert c2g[0] == pytest.approx(oracle.region_mean(img, u_c, 1), rel=1e-9)
+
+
+def test_resident_chunks_continuation_and_mixing(capi, oracle):
+    """Chunk boundaries (enqueue 5 + 8 + 1), a second run from the result, then the per-launch flow from the resident result and
+    back: all equal the oracle's 30 iterations; the resident flow is bitwise repeatable."""
+    h, w = 160, 384
+    img = synth.disk(160, 200, 50, noise=12, seed=9, h=h, w=w)
+    u0 = oracle.checkerboard(h, w)
+    pk = dict(tol=0)
+    u_c, _, _, tr_c = oracle.csv_run([img], u0, oracle.make_params(**pk), 30)
+    outs = []
+    for rep in range(2):
+        ctx, _ = resident_ctx(capi, h, w, pk)
+        with ctx:
+            ctx.set_option("trace", 64)
+            ctx.set_image([img])
+            ctx.set_levelset(u0)
+            ctx.enqueue_steps(5); ctx.enqueue_steps(8); ctx.enqueue_steps(1)
+            done, _, stopped = ctx.sync()
+            assert done == 14 and not stopped
+            assert np.allclose(ctx.get_trace(14), tr_c[:14], rtol=1e-9, atol=0)
+            assert ctx.run(6)[0] == 6                     # resident, continues from the level set in memory
+            ctx.set_option("resident", 0)
+            assert ctx.launch_info()["kernel"].startswith("csv_wave")
+            assert ctx.run(7)[0] == 7                     # per-launch flow from the resident result
+            ctx.set_option("resident", 1)
+            assert ctx.run(3)[0] == 3                     # and back
+            outs.append(ctx.get_levelset())
+    assert rel_err(outs[0], u_c) <= 1e-9
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_resident_stop_rule_same_iteration(capi, oracle):
+    """The stop rule is booked at the grid barrier of the iteration itself: the run ends at the reference's iteration (first
+    chunk, middle of a chunk), and the level set is the reference's."""
+    img = synth.disk(128, 200, 50)
+    u0 = oracle.checkerboard(128, 128)
+    for tol in (1e-3, 0.05, 0.5):
+        u_c, done_c, nrm_c, _ = oracle.csv_run([img], u0, oracle.make_params(tol=tol), 400)
+        for sync_every in (1, 7, 32):
+            ctx, _ = resident_ctx(capi, 128, 128, dict(tol=tol))
+            with ctx:
+                ctx.set_option("sync_every", sync_every)
+                ctx.set_image([img])
+                ctx.set_levelset(u0)
+                done_g, nrm_g = ctx.run(400)
+                u_g = ctx.get_levelset()
+            assert done_g == done_c, (tol, sync_every, done_g, done_c)
+            assert nrm_g == pytest.approx(nrm_c, rel=1e-7)
+            assert rel_err(u_g, u_c) <= 1e-6
+
+
+def test_resident_2048_against_the_exact_sum_oracle(capi, oracle):
+    """The configuration this flow exists for: 2048 x 2048, 16 x 16 tiles of 128 x 128 on 256 CUs, 8 iterations from the checkerboard
+    against the oracle with exact region sums (tests/test_gpu_fullsize.py, check (d)): <= 1e-9 on every iteration; and against
+    the per-launch flow of the library."""
+    n, steps = 2048, 8
+    img = synth.config_planes("C4", n)
+    u0 = oracle.checkerboard(n, n)
+    p = oracle.make_params(tol=0)
+    u_e, tr_e = u0.copy(), []
+    for t in range(steps):
+        nrm, c1, c2 = oracle.csv_step_exact(img, u_e, p)
+        tr_e.append(list(c1) + list(c2) + [nrm])
+    ctx, info = resident_ctx(capi, n, n, dict(tol=0))
+    assert info["tiles_y"] == "16" and info["tiles_x"] == "16", info
+    with ctx:
+        ctx.set_option("trace", steps)
+        ctx.set_image(img)
+        ctx.set_levelset(u0)
+        assert ctx.run(steps)[0] == steps
+        u_g, tr_g = ctx.get_levelset(), ctx.get_trace(steps)
+        ctx.set_option("resident", 0)
+        ctx.set_levelset(u0)
+        assert ctx.run(steps)[0] == steps
+        u_l = ctx.get_levelset()
+    assert rel_err(u_g, u_e) <= 1e-9, rel_err(u_g, u_e)
+    assert np.allclose(tr_g, np.array(tr_e), rtol=1e-9, atol=0)
+    assert rel_err(u_g, u_l) <= 1e-9
