@@ -325,6 +325,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (c->d_dbg) { HIPCHK(c, hipFree(c->d_dbg)); c->d_dbg = nullptr; c->dbg_words = 0; }
     if (value > 0) {
       c->dbg_words = (size_t)c->partial_rows * 20 + 16;
+      if (c->dbg_words < (size_t)CVH_RESIDENT_MAX_TILES * 12) c->dbg_words = (size_t)CVH_RESIDENT_MAX_TILES * 12;   // resident kernel: 12 words per tile
       HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
       HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
     }
@@ -1001,7 +1002,7 @@ static int launch_resident(cvh_context *c, const ResidentGeom &rg, int nsteps, C
     a.res_poll_cap = 2000000;      // seconds of polling before a wait gives up (the grid always drains)
     a.note = note;
     if (note) { HIPCHK(c, cvh_launch_resident(a, c->stream)); return CVH_OK; }
-    HIPCHK(c, hipMemsetAsync(c->d_resident, 0, 64 + (size_t)ntiles * 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_resident, 0, sizeof(CvhResident), c->stream));
     HIPCHK(c, cvh_launch_resident(a, c->stream));
     c->chain_pending = true;       // the flush kernel writes c1 / c2 of the final level set into the state block at the next sync
     c->resident_used = true;
@@ -1081,14 +1082,13 @@ static int sync_impl(cvh_context *c)
   if (rc != CVH_OK) return rc;
   if (c->timing_open) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   if (!via_flush) HIPCHK(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(CvhState), hipMemcpyDeviceToHost, c->stream));
-  if (c->resident_used) HIPCHK(c, hipMemcpyAsync(c->h_resident, c->d_resident, 8, hipMemcpyDeviceToHost, c->stream));
+  if (c->resident_used) HIPCHK(c, hipMemcpyAsync(c->h_resident, c->d_resident, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->resident_used) {
     c->resident_used = false;
-    if (c->h_resident[1]) {
+    if (c->h_resident[0]) {
       c->timing_open = false;
-      return fail(c, CVH_ERR_HIP, "the resident step kernel gave up waiting for a workgroup (%d arrivals): the level set of this run is invalid",
-                  c->h_resident[0]);
+      return fail(c, CVH_ERR_HIP, "the resident step kernel gave up waiting for a workgroup: the level set of this run is invalid");
     }
   }
   if (via_flush) {
@@ -1477,17 +1477,18 @@ extern "C" int cvh_launch_info(cvh_context *c, int phase, char *buf, int cap)
   return CVH_OK;
 }
 
-// Diagnostic (not part of include/chanvese_hip.h): the synchronisation words of the last resident launch: {arrive, error, go[0 .. n)}.
+// Diagnostic (not part of include/chanvese_hip.h): the synchronisation words of the last resident launch: {error, 0, generation of
+// the arrival line of tile 0 .. n-1, generation of the release line of tile 0 .. n-1}.
 extern "C" int cvh_debug_resident_read(cvh_context *c, unsigned *out, int ngo)
 {
   if (!c || !out || ngo < 0 || ngo > CVH_RESIDENT_MAX_TILES) return CVH_ERR_ARG;
   if (!c->d_resident) return fail(c, CVH_ERR_STATE, "no resident launch yet");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::vector<unsigned> tmp(16 + (size_t)ngo * 16);
-  HIPCHK(c, hipMemcpy(tmp.data(), c->d_resident, tmp.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-  out[0] = tmp[0]; out[1] = tmp[1];
-  for (int i = 0; i < ngo; ++i) out[2 + i] = tmp[16 + (size_t)i * 16];
+  std::vector<unsigned> tmp(sizeof(CvhResident) / sizeof(unsigned));
+  HIPCHK(c, hipMemcpy(tmp.data(), c->d_resident, sizeof(CvhResident), hipMemcpyDeviceToHost));
+  out[0] = tmp[0]; out[1] = 0;
+  for (int i = 0; i < ngo; ++i) { out[2 + i] = tmp[16 + (size_t)i * 16]; out[2 + ngo + i] = tmp[16 + (size_t)CVH_RESIDENT_MAX_TILES * 16 + (size_t)i * 16]; }
   return CVH_OK;
 }
 

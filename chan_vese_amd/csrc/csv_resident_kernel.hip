@@ -35,7 +35,10 @@ namespace {
 constexpr int RT_W = 128;                 // tile width: 64 lanes x 2 pixels
 constexpr int RT_HMAX = 128;              // most rows a tile may have (LDS)
 constexpr int RT_PITCH = 132;             // doubles per LDS row: tile columns -2 .. 129
-constexpr int RT_THREADS = 512, RT_WAVES = 8;
+#ifndef CVH_RT_WAVES
+#define CVH_RT_WAVES 8                    // waves per workgroup (A/B builds: 16 = 4 per SIMD at <= 128 VGPRs)
+#endif
+constexpr int RT_WAVES = CVH_RT_WAVES, RT_THREADS = 64 * RT_WAVES;
 constexpr int RT_HALO = 6 * RT_W;         // doubles a tile publishes per iteration: bottom 2 rows, top row, right 2 columns, left column
 constexpr int kWordStride = 16;           // one synchronisation word per 64 bytes
 constexpr unsigned kAbort = 0xffffffffu;
@@ -50,7 +53,7 @@ struct ResSmem {
   static constexpr int off_nxl = off_atan + CVH_ATAN2_N + 1;                // RT_HMAX: normalised x-gradient of column -1
   static constexpr int off_red = off_nxl + RT_HMAX;                         // RT_WAVES x NS
   static constexpr int off_flag = off_red + RT_WAVES * NS;
-  static constexpr int doubles = off_flag + 2;
+  static constexpr int doubles = off_flag + 4 + (RT_WAVES + 1) / 2 + 1;   // 3 broadcast doubles, then ints
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
 static_assert(ResSmem::bytes <= 160 * 1024, "the tile, its halo ring and the tables must fit one CU's LDS");
@@ -79,33 +82,46 @@ __device__ __forceinline__ void block_reduce8(double (&acc)[NS], double *sred /*
   for (int s = 0; s < NS; ++s) {
     double t = sred[s];
 #pragma unroll
-    for (int wv = 1; wv < RT_WAVES; ++wv) t += sred[wv * NS + s];
+    for (int wv = 1; wv < RT_WAVES; ++wv) t += sred[wv * NS + s];   // fixed order
     total[s] = t;
   }
   __syncthreads();
 }
 
-// Thread 0 polls this workgroup's "go" word until it reaches iteration `it` (bounded); the workgroup meets at a barrier.
-// Returns the word (bit 0: leave), or kAbort.
-__device__ __forceinline__ unsigned wg_wait_go(const unsigned *p, int it, const CvhStepArgs &a, int *s_flag)
+// 16-byte agent-scope (sc1) accesses to the synchronisation lines: one lane, one transaction.
+typedef unsigned int u32x4r_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4r_t ld_line16(const void *base, unsigned byte_off)
+{
+  return __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, 0x7fffffffu), byte_off, 0u, 16 /* sc1 */);
+}
+__device__ __forceinline__ void st_line16(void *base, unsigned byte_off, unsigned w0, unsigned w1, double d)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4r_t{w0, w1, (unsigned)b, (unsigned)(b >> 32)}, make_rsrc(base, 0x7fffffffu), byte_off, 0u, 16 /* sc1 */);
+}
+__device__ __forceinline__ double line16_f64(u32x4r_t v) { return __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z)); }
+
+// Thread 0 polls this workgroup's release line until both halves carry generation >= `gen` (bounded); the workgroup meets at a
+// barrier.  Returns the leave bit (or -1: gave up) and the region means the line carries.
+__device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int gen, const CvhStepArgs &a, double *s_bc /*[4]*/, double &c1, double &c2)
 {
   if (threadIdx.x == 0) {
-    unsigned v = kAbort;
-    int ok = 0;
+    int res = -1;
+    double m1 = 0.0, m2 = 0.0;
     for (int i = 0; i < a.res_poll_cap; ++i) {
-      v = ld_agent(p);
-      if (v == kAbort) break;
-      if ((v >> 1) >= (unsigned)it) { ok = 1; break; }
-      if (ld_agent((const unsigned *)&a.resident->error) != 0u) break;
-      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(4);
+      const u32x4r_t ga = ld_line16(rs->go, (unsigned)bid * 64u), gb = ld_line16(rs->go, (unsigned)bid * 64u + 16u);
+      if (ga.x == gb.x && ga.x >= (unsigned)gen && ga.x != 0xffffffffu) { res = (int)(ga.y & 1u); m1 = line16_f64(ga); m2 = line16_f64(gb); break; }
+      if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(3);
     }
-    if (!ok) { st_agent(&a.resident->error, 1); v = kAbort; }
-    *s_flag = (int)v;
+    if (res < 0) st_agent(const_cast<int *>(&rs->error), 1);
+    s_bc[0] = (double)res; s_bc[1] = m1; s_bc[2] = m2;
   }
   __syncthreads();
-  const unsigned v = (unsigned)*s_flag;
+  const int res = (int)s_bc[0];
+  c1 = s_bc[1]; c2 = s_bc[2];
   __syncthreads();
-  return v;
+  return res;
 }
 
 __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhStepArgs a)
@@ -119,7 +135,8 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   double *satan = smem + L::off_atan;
   double *snxl = smem + L::off_nxl;
   double *sred = smem + L::off_red;
-  int *s_flag = (int *)(smem + L::off_flag);
+  double *s_bc = smem + L::off_flag;      // 4 doubles of broadcast scratch
+  int *s_flag = (int *)(s_bc + 3);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -159,6 +176,19 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     const int gr = clampi(r0 + r, 0, h - 1), gc = clampi(c0 + c, 0, w - 1);
     su[q] = a.u_in[(size_t)gr * w + gc];
   }
+  // Sum sets (chain_device.h): iteration `it` of this launch reads set p0 + it and adds into p0 + it + 1.  p0 + 1 is clear by the
+  // per-launch invariant; p0 + 2 and p0 + 3 are cleared here (long before anybody adds into them: a grid barrier lies between), and from
+  // then on every barrier clears the set that was just consumed.  The invariant holds again when the launch ends.
+  if (bid == 0 && tid < 128)
+    __hip_atomic_store(&a.chain->v[(a.chain_phase + 2 + (tid >> 6)) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // region means of the level set the launch starts from (later iterations get theirs with the release)
+  double c1, c2;
+  {
+    const long long entry = a.chain->v[a.chain_phase & 3][lane];
+    double m1[1], m2[1];
+    chain_means<1>(a, entry, m1, m2);
+    c1 = m1[0]; c2 = m2[0];
+  }
   __syncthreads();
 
   const double l1 = a.lambda1[0], l2 = a.lambda2[0];
@@ -173,58 +203,33 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   double *const halo_mine[2] = {a.res_halo + (size_t)bid * RT_HALO, a.res_halo + ((size_t)ntiles + bid) * RT_HALO};
   auto norm = [&](double fwd, double bwd, double c) -> double { return normalised4(fwd, bwd, c + c); };
 
+  // diagnostic stamps (option "debug_times", tools/resident_timeline.py): 12 words per workgroup, taken around iteration kStampIt
+  constexpr int kStampIt = 3;
+  auto stamp = [&](int it_now, int it_want, int slot) {
+    if (a.dbg_times && it_now == it_want && tid == 0) a.dbg_times[(size_t)bid * 12 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
   int executed = 0;
+  bool gave_up = false;
   const int nit = a.res_steps;
   for (int it = 0; it < nit; ++it) {
     const int phase = (a.chain_phase + it) & 3;
-    // ---- the grid barrier behind iteration it - 1, then its halos (iteration 0 loaded them with the tile)
+    // ---- the release behind iteration it - 1: leave bit and the region means of u(it); the halos were fetched while waiting
     if (it > 0) {
-      const unsigned go = wg_wait_go(&rs->go[(size_t)bid * kWordStride], it, a, s_flag);
-      if (go == kAbort || (go & 1u)) break;
-      const double *const hb = a.res_halo + (size_t)((it - 1) & 1) * ntiles * RT_HALO;
-      // top halo rows -2, -1 <- the tile above's bottom two rows; bottom halo row TH <- the tile below's top row;
-      // left halo columns -2, -1 <- the left tile's right two columns; right halo column TWv <- the right tile's left column;
-      // at the image's border: BORDER_REPLICATE from the tile's own edge (src/main.cpp:351-354)
-      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
-        const int piece = q / RT_W, k = q % RT_W;
-        double v;
-        double *dst;
-        if (piece < 2) {            // top rows
-          dst = S(piece - 2, k);
-          v = ty > 0 ? ld_agent_f64(hb + (size_t)(bid - tc) * RT_HALO + piece * RT_W + k) : *S(0, k);
-        } else if (piece == 2) {    // bottom row
-          dst = S(TH, k);
-          v = ty < tr - 1 ? ld_agent_f64(hb + (size_t)(bid + tc) * RT_HALO + 2 * RT_W + k) : *S(TH - 1, k);
-        } else if (piece < 5) {     // left columns
-          dst = S(k < TH ? k : 0, piece - 5);
-          v = tx > 0 ? ld_agent_f64(hb + (size_t)(bid - 1) * RT_HALO + piece * RT_W + k) : *S(k < TH ? k : 0, 0);
-          if (k >= TH) dst = nullptr;
-        } else {                    // right column
-          dst = S(k < TH ? k : 0, TWv);
-          v = tx < tc - 1 ? ld_agent_f64(hb + (size_t)(bid + 1) * RT_HALO + 5 * RT_W + k) : *S(k < TH ? k : 0, TWv - 1);
-          if (k >= TH) dst = nullptr;
-        }
-        if (dst) *dst = v;
-      }
+      const int go = wg_wait_go(rs, bid, it, a, s_bc, c1, c2);
+      if (go < 0) { gave_up = true; break; }
+      if (go & 1) break;
     }
-    // ---- region means of u(it) from the fixed-point sums, table of the variance term (:307-310, :979, :985)
-    double c1, c2;
-    {
-      const long long entry = __hip_atomic_load(&a.chain->v[phase][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      double m1[1], m2[1];
-      chain_means<1>(a, entry, m1, m2);
-      c1 = m1[0]; c2 = m2[0];
-      if (tid < 256) {
-        const double v = (double)tid;
-        const double d1 = v - c1, d2 = v - c2;
-        const double reg = (d2 * d2) * l2 - (d1 * d1) * l1;
-        slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
-        slut[2 * tid + 1] = v;
-      }
+    stamp(it, kStampIt, 0); stamp(it, kStampIt + 1, 8);       // released into this iteration
+    // ---- table of the variance term (:307-310, :979, :985)
+    if (tid < 256) {
+      const double v = (double)tid;
+      const double d1 = v - c1, d2 = v - c2;
+      const double reg = (d2 * d2) * l2 - (d1 * d1) * l1;
+      slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
+      slut[2 * tid + 1] = v;
     }
-    __syncthreads();
     // ---- normalised x-gradient of tile column -1, one thread per row (nobody owns that column; lane 0 needs it for column 0)
-    if (tid < TH) snxl[tid] = norm(*S(tid, 0), *S(tid, -2), *S(tid, -1));
+    if (tid >= 256 && tid - 256 < TH) snxl[tid - 256] = norm(*S(tid - 256, 0), *S(tid - 256, -2), *S(tid - 256, -1));
     // ---- every wave takes the rows around its band into registers before any wave writes
     const double2_t um2_0 = *reinterpret_cast<const double2_t *>(S(rb0 - 2, ca));
     double2_t um = *reinterpret_cast<const double2_t *>(S(rb0 - 1, ca));
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     double uw = *S(rb0, ca - 1), ue = *S(rb0, ca + 2);
     const double2_t u1st = *reinterpret_cast<const double2_t *>(S(rb0 + 1 < rb1 ? rb0 + 1 : rb0, ca));   // row rb0 + 1 (own band, if it has one)
     __syncthreads();
+    stamp(it, kStampIt, 1);                                    // table in LDS, band borders in registers
 
     double acc[NS];
 #pragma unroll
@@ -243,11 +249,30 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         const double2_t up0 = (rb0 + 1 < rb1) ? u1st : ubot;
         nypa = norm(up0.x, um.x, u0.x); nypb = norm(up0.y, um.y, u0.y);
       }
-      for (int i = rb0; i < rb1; ++i) {
+      auto pixel = [&](double c, double n_, double s_, double nx, double nxl, double fx, double &nyp, int byte, double &ud_out,
+                       double &Ik_out) -> double {
+        const double ny = norm(s_, n_, c);
+        const double kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
+        const double2_t e = reinterpret_cast<const double2_t *>(slut)[byte];
+        double ud = __builtin_fma(kappa, a.alpha, e.x);                  // :985
+        const double qd = __builtin_fma(c, c, eps2) * a.dk1;             // 1 / delta_eps(u)
+        const double q0 = __builtin_amdgcn_rcp(qd);
+        const double er = __builtin_fma(-qd, q0, 1.0);
+        ud = ud * __builtin_fma(__builtin_fma(er, er, er), q0, q0);      // :992
+        nyp = ny;
+        ud_out = ud; Ik_out = e.y;
+        return c + ud;                                                   // :994
+      };
+      // One row: everything up to the new values and the far-field form of H - 1/2 on every lane (branch-free); the lanes near
+      // the contour are corrected per group of four rows (csv_wave2_kernel.hip, DEFER)
+      double2_t keep[4];
+      int smp_keep[4];
+      unsigned long long near_mask[4];
+      auto row = [&](int i, int k) {
         const bool lastrow = i + 1 >= rb1;                      // wave-uniform
         double2_t up;
         double uw_n = 0.0, ue_n = 0.0;
-        if (lastrow) up = ubot;
+        if (lastrow) up = ubot;                                 // the band below may have rewritten its first row already
         else {
           up = *reinterpret_cast<const double2_t *>(S(i + 1, ca));
           uw_n = *S(i + 1, ca - 1); ue_n = *S(i + 1, ca + 2);
@@ -260,43 +285,51 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         const double nxb = norm(ue, u0.x, u0.y);
         const double nxla_d = dpp_from_left(nxb);
         const double nxla = lane == 0 ? nxl0 : nxla_d;
-        auto pixel = [&](double c, double n_, double s_, double nx, double nxl, double fx, double &nyp, int byte, double &ud_out,
-                         double &Ik_out) -> double {
-          const double ny = norm(s_, n_, c);
-          const double kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
-          const double2_t e = reinterpret_cast<const double2_t *>(slut)[byte];
-          double ud = __builtin_fma(kappa, a.alpha, e.x);                  // :985
-          const double qd = __builtin_fma(c, c, eps2) * a.dk1;             // 1 / delta_eps(u)
-          const double q0 = __builtin_amdgcn_rcp(qd);
-          const double er = __builtin_fma(-qd, q0, 1.0);
-          ud = ud * __builtin_fma(__builtin_fma(er, er, er), q0, q0);      // :992
-          nyp = ny;
-          ud_out = ud; Ik_out = e.y;
-          return c + ud;                                                   // :994
-        };
         double uda, udb, Ia, Ib;
         const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nypa, ba, uda, Ia);
         const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nypb, bb, udb, Ib);
-        double hva, hvb;
-        if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {   // far / near decided per wave
-          hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
-        } else {
-          hva = heaviside_centred_near(va, a.inv_eps, satan); hvb = heaviside_centred_near(vb, a.inv_eps, satan);
-        }
-        if (lane_valid) *reinterpret_cast<double2_t *>(S(i, ca)) = double2_t{va, vb};   // in place: every reader of the old row i has it in registers
+        keep[k] = double2_t{va, vb};
+        smp_keep[k] = smp;
+        const double hva = heaviside_centred_far(va, fc), hvb = heaviside_centred_far(vb, fc);
+        near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
+        if (lane_valid) *reinterpret_cast<double2_t *>(S(i, ca)) = keep[k];   // in place: every reader of the old row i has it in registers
         acc[0] += hva; acc[0] += hvb;
         acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
         acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
         um = u0; u0 = up; uw = uw_n; ue = ue_n;
+      };
+      auto correct = [&](int k) {
+        if (near_mask[k] != 0ull) {
+          const double xa = keep[k].x, xb = keep[k].y;
+          const double da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
+          const double db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
+          acc[0] += da; acc[0] += db;
+          acc[2] = __builtin_fma((double)(smp_keep[k] & 0xff), da, acc[2]);
+          acc[2] = __builtin_fma((double)(smp_keep[k] >> 8), db, acc[2]);
+        }
+      };
+      int i = rb0;
+      for (; i + 4 <= rb1; i += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) row(i + k, k);
+        if ((near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) correct(k);
+        }
       }
+      for (; i < rb1; ++i) { row(i, 0); correct(0); }
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;   // exact: lanes beyond the image contribute nothing
     }
+    stamp(it, kStampIt, 2);                                    // (thread 0's wave) march done
     double total[NS];
     block_reduce8<NS>(acc, sred, total);    // (its barriers also order the tile writes before the border reads below)
+    stamp(it, kStampIt, 3);                                    // all waves done, sums reduced
     executed = it + 1;
+    const unsigned gen = (unsigned)(it + 1);
 
-    // ---- publish: fixed-point sums for the next iteration's means, the sum u_diff^2 row, the tile's border for the neighbours
+    // ---- publish: fixed-point sums for the next iteration's means, the tile's border for the neighbours; then ONE 16-byte line
+    // {generation, sum u_diff^2}: the arrival (distinct addresses: 256 arrivals on one counter serialise for 6 us)
     {
       long long *const set = &a.chain->v[(phase + 1) & 3][0];
       const int shard = bid % chain_shards<1>();
@@ -305,7 +338,6 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       if (tid == 64)
         __hip_atomic_fetch_add(&set[chain_shards<1>() + shard], __double2ll_rn(total[2] * a.chain_scale[1]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 128) st_agent_f64(&a.chain_s4[(size_t)(phase & 1) * ntiles + bid], total[4]);
     }
     {
       double *const hb = halo_mine[it & 1];
@@ -319,60 +351,125 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         st_agent_f64(hb + q, v);
       }
     }
-    // ---- arrive; the last workgroup to arrive books the iteration and releases everybody
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(&rs->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_flag = (old + 1u == (unsigned)(it + 1) * (unsigned)ntiles) ? 1 : 0;
-    }
-    __syncthreads();
-    const int last = *s_flag;
-    __syncthreads();
-    if (last) {
-      // iteration `it` is complete everywhere: norm (fixed order), trace row, stop rule (src/main.cpp:993-1000)
+    stamp(it, kStampIt, 4);                                    // sums and borders have reached memory
+    if (tid == 0) st_line16(rs->flag, (unsigned)bid * 64u, gen, 0u, total[4]);
+
+    // ---- workgroup 0 is the barrier's master: it watches the arrival lines, books the iteration and releases everybody
+    if (bid == 0) {
+      double s4 = 0.0;
+      bool mine_ok = true;
+      int ok_all = 0;
+      for (int round = 0; round < a.res_poll_cap; ++round) {
+        bool ok = true;
+        double part = 0.0;
+        for (int b = tid; b < ntiles; b += RT_THREADS) {         // fixed order per thread: b ascending
+          const u32x4r_t f = ld_line16(rs->flag, (unsigned)b * 64u);
+          ok = ok && (f.x >= gen) && (f.x != 0xffffffffu);
+          part += line16_f64(f);
+        }
+        mine_ok = ok; s4 = part;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
+        if (lane == 0) s_flag[wave] = (bal == ~0ull) ? 1 : 0;     // (s_flag: ints behind the broadcast doubles; RT_WAVES <= 16 fit)
+        __syncthreads();
+        int all = 1;
+#pragma unroll
+        for (int wv = 0; wv < RT_WAVES; ++wv) all &= s_flag[wv];
+        __syncthreads();
+        if (all) { ok_all = 1; break; }
+        if ((round & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      (void)mine_ok;
+      if (!ok_all) { if (tid == 0) st_agent(&rs->error, 1); gave_up = true; break; }
+      if (a.dbg_times && it == kStampIt && tid == 0) a.dbg_times[5] = __builtin_amdgcn_s_memrealtime();   // master: everybody has arrived
+      // iteration `it` is complete everywhere: norm (fixed order), stop rule (src/main.cpp:993-1000), region means of u(it + 1)
+      const long long entry_n = __hip_atomic_load(&a.chain->v[(phase + 1) & 3][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       double nacc[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) nacc[s] = 0;
-      const double *rows = a.chain_s4 + (size_t)(phase & 1) * ntiles;
-      for (int b = tid; b < ntiles; b += RT_THREADS) nacc[0] += ld_agent_f64(&rows[b]);
+      nacc[0] = s4;
       double ntot[NS];
       block_reduce8<NS>(nacc, sred, ntot);
-      if (tid < 64) __hip_atomic_store(&a.chain->v[(phase + 2) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the set iteration it + 1 adds into
-      int stop_now = 0;
+      const double nrm = sqrt(ntot[0]);
+      const int stop_now = nrm <= a.stop_cond;          // :1000, after the update (the same value in every thread)
+      double n1[1], n2[1];
+      chain_means<1>(a, entry_n, n1, n2);
+      const unsigned leave = (stop_now || it + 1 >= nit) ? 1u : 0u;
+      stamp(it, kStampIt, 6);                                  // master: norm and means known
+      for (int i = tid; i < ntiles; i += RT_THREADS) {
+        st_line16(rs->go, (unsigned)i * 64u, gen, leave, n1[0]);
+        st_line16(rs->go, (unsigned)i * 64u + 16u, gen, leave, n2[0]);
+      }
+      stamp(it, kStampIt, 7);                                  // master: release issued
+      // everything else the master books comes AFTER the release (off the critical path of the other workgroups)
+      // the set everybody consumed in this iteration is the add target three iterations on: cleared now, two barriers ahead
+      if (tid >= 64 && tid < 128) __hip_atomic_store(&a.chain->v[phase][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid == 0) {
         CvhState *st = a.st;
-        const int t = t_first + it;                      // (not read back: another XCD's L2 may hold a stale copy)
-        const double nrm = sqrt(ntot[0]);
-        // state words and trace rows are written by whichever workgroup arrives last -- a different XCD from one iteration to the
-        // next: write-through (agent-scope) stores, or two XCDs' L2s would race to write the same word back at the end of the kernel
-        if (a.trace && t < a.trace_cap) {
-          st_agent_f64(&a.trace[(size_t)t * 3], c1); st_agent_f64(&a.trace[(size_t)t * 3 + 1], c2); st_agent_f64(&a.trace[(size_t)t * 3 + 2], nrm);
-        }
-        st_agent_f64(&st->norm, nrm);
-        st_agent(&st->steps_done, t + 1);
-        st_agent(&st->pending, 0);
-        stop_now = nrm <= a.stop_cond;                  // :1000, after the update
-        if (stop_now) st_agent(&st->stopped, 1);
+        const int t = t_first + it;
+        if (a.trace && t < a.trace_cap) { a.trace[(size_t)t * 3] = c1; a.trace[(size_t)t * 3 + 1] = c2; a.trace[(size_t)t * 3 + 2] = nrm; }
+        st->norm = nrm;
+        st->steps_done = t + 1;
+        st->pending = 0;
+        if (stop_now) st->stopped = 1;
         if (a.host_status) {
           __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        *s_flag = stop_now;
+      }
+    }
+
+    // ---- while the barrier completes: the neighbours' borders of u(it + 1) (they exist as soon as the up-to-four neighbours have
+    // arrived), into the halo ring; at the image's border: BORDER_REPLICATE from the tile's own edge (src/main.cpp:351-354)
+    if (it + 1 < nit) {
+      if (tid < 64) {
+        const int nb = lane == 0 ? (ty > 0 ? bid - tc : -1) : lane == 1 ? (ty < tr - 1 ? bid + tc : -1) : lane == 2 ? (tx > 0 ? bid - 1 : -1)
+                       : lane == 3 ? (tx < tc - 1 ? bid + 1 : -1) : -1;
+        bool sat = nb < 0;
+        int ok = 0;
+        for (int i = 0; i < a.res_poll_cap; ++i) {
+          if (!sat) { const u32x4r_t f = ld_line16(rs->flag, (unsigned)(nb < 0 ? 0 : nb) * 64u); sat = f.x >= gen && f.x != 0xffffffffu; }
+          if (__builtin_amdgcn_ballot_w64(!sat) == 0ull) { ok = 1; break; }
+          if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane == 0) { if (!ok) st_agent(&rs->error, 1); s_flag[0] = ok; }
       }
       __syncthreads();
-      stop_now = *s_flag;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int okn = s_flag[0];
       __syncthreads();
-      const unsigned val = ((unsigned)(it + 1) << 1) | ((stop_now || it + 1 >= nit) ? 1u : 0u);
-      for (int i = tid; i < ntiles; i += RT_THREADS) st_agent(&rs->go[(size_t)i * kWordStride], val);
+      if (!okn) { gave_up = true; break; }
+      const double *const hbn = a.res_halo + (size_t)(it & 1) * ntiles * RT_HALO;
+      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
+        const int piece = q / RT_W, k = q % RT_W;
+        double v;
+        double *dst;
+        if (piece < 2) {            // top halo rows -2, -1 <- the tile above's bottom two rows
+          dst = S(piece - 2, k);
+          v = ty > 0 ? ld_agent_f64(hbn + (size_t)(bid - tc) * RT_HALO + piece * RT_W + k) : *S(0, k);
+        } else if (piece == 2) {    // bottom halo row TH <- the tile below's top row
+          dst = S(TH, k);
+          v = ty < tr - 1 ? ld_agent_f64(hbn + (size_t)(bid + tc) * RT_HALO + 2 * RT_W + k) : *S(TH - 1, k);
+        } else if (piece < 5) {     // left halo columns -2, -1 <- the left tile's right two columns
+          dst = k < TH ? S(k, piece - 5) : nullptr;
+          v = tx > 0 ? ld_agent_f64(hbn + (size_t)(bid - 1) * RT_HALO + piece * RT_W + k) : *S(k < TH ? k : 0, 0);
+        } else {                    // right halo column TWv <- the right tile's left column
+          dst = k < TH ? S(k, TWv) : nullptr;
+          v = tx < tc - 1 ? ld_agent_f64(hbn + (size_t)(bid + 1) * RT_HALO + 5 * RT_W + k) : *S(k < TH ? k : 0, TWv - 1);
+        }
+        if (dst) *dst = v;
+      }
+      // (the barrier at the top of the next iteration orders these LDS writes before their readers)
     }
   }
-  // ---- leave: every workgroup waits for the release behind the last iteration it computed (the bookkeeping of that iteration
-  // is then complete), then writes its tile back into the ping-pong buffer the per-launch path would hold the result in
+  if (gave_up) return;
+  // ---- leave: every workgroup waits for the release behind the last iteration it computed (the whole grid has then finished it),
+  // then writes its tile back into the ping-pong buffer the per-launch path would hold the result in
   if (executed > 0) {
-    const unsigned go = wg_wait_go(&rs->go[(size_t)bid * kWordStride], executed, a, s_flag);
-    if (go == kAbort) return;
+    double d1, d2;
+    if (wg_wait_go(rs, bid, executed, a, s_bc, d1, d2) < 0) return;
   }
   // (an even count lands in the buffer the launch read from: every workgroup has long finished reading it -- the first grid
   // barrier lies behind all the tile loads)

@@ -45,10 +45,14 @@ struct CvhChainAcc { long long v[CVH_CHAIN_SETS][64]; };
 // Resident kernel (csv_resident_kernel.hip): the words its workgroups synchronise on, zeroed before every launch.
 constexpr int CVH_RESIDENT_MAX_TILES = 1024;
 struct CvhResident {
-  unsigned arrive;      // workgroups that finished an iteration, cumulative over the launch (iteration e complete: (e + 1) * tiles)
   int error;            // a bounded wait gave up (a workgroup was not resident, or a fault): the launch drains, the host reports it
-  unsigned pad[14];
-  unsigned go[CVH_RESIDENT_MAX_TILES * 16];   // per workgroup, one word per 64 bytes: (iterations complete) << 1 | leave
+  unsigned pad[15];
+  // one 64-byte line per tile, written as ONE 16-byte agent-scope store {generation, 0, sum u_diff^2 of the tile}: the tile has finished
+  // iteration generation - 1 of the launch and its borders and sums are in memory (arrivals on distinct addresses do not serialise)
+  unsigned flag[CVH_RESIDENT_MAX_TILES * 16];
+  // one 64-byte line per tile, written by the master as two 16-byte stores {generation, leave, c1} {generation, leave, c2}: the release
+  // behind iteration generation - 1 and the region means of the level set it produced
+  unsigned go[CVH_RESIDENT_MAX_TILES * 16];
 };
 
 // Sums carried per workgroup and reduced in a fixed order (deterministic):

@@ -1,0 +1,37 @@
+"""Where an iteration of the resident kernel (csv_resident_kernel.hip) spends its time: per-workgroup stamps around iteration 3 of one
+cooperative launch.  usage: N=2048 python tools/resident_timeline.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, '.')
+import numpy as np
+from chan_vese_amd import capi, synth
+n = int(os.environ.get("N", "2048"))
+ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
+ctx.set_option("resident", 1)
+for kv in sys.argv[1:]:
+    k, v = kv.split("="); ctx.set_option(k, int(v))
+info = ctx.launch_info(); assert info["kernel"] == "csv_resident_kernel", info
+nt = int(info["grid"])
+ctx.set_image([synth.disk(n)]); ctx.init_checkerboard()
+ctx.run(100)
+ctx.set_option("debug_times", 1)
+ctx.run(8)
+L = capi.lib()
+L.cvh_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+buf = np.zeros(nt * 12 + 64, dtype=np.uint64); words = C.c_long(0); nb = C.c_int(0)
+L.cvh_debug_read(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size, C.byref(words), C.byref(nb))
+w = buf[:nt * 12].reshape(nt, 12).astype(np.int64)
+t0 = w[:, 0].min()
+us = lambda x: (x - t0) / 100.0
+names = ["released into it 3", "table in LDS, band borders read", "march done (wave 0)", "all waves done, sums reduced", "sums + borders in memory",
+         "master: everybody has arrived", "master: norm and means known", "master: release issued", "released into it 4"]
+print("tiles", nt, info)
+for k, nm in enumerate(names):
+    col = w[:, k]; ok = col > 0
+    if ok.sum() == 0: continue
+    v = us(col[ok])
+    print("%-34s n %4d  min %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (nm, ok.sum(), v.min(), np.median(v), np.percentile(v, 90), v.max()))
+d = lambda a_, b_: np.median((w[:, b_] - w[:, a_]) / 100.0)
+print("per workgroup (median): set-up %.2f | march (wave 0) %.2f | other waves + reduce %.2f | publish (stores complete) %.2f us" % (d(0, 1), d(1, 2), d(2, 3), d(3, 4)))
+print("last tile's stores complete %.2f -> master sees all arrivals %.2f -> norm / means %.2f -> release issued %.2f -> seen by the others: p50 %.2f max %.2f ; iteration period (p50) %.2f us" % (
+    us(w[:, 4]).max(), us(w[0, 5]), us(w[0, 6]), us(w[0, 7]), np.median(us(w[:, 8])), us(w[:, 8]).max(), np.median((w[:, 8] - w[:, 0]) / 100.0)))
+ctx.close()

@@ -7,3 +7,5 @@ timeout -k 10 600 python -m pytest tests/test_gpu_resident.py -m gpu -x -q --dur
 N=2048 REPS=3 STEPS=200 timeout -k 10 300 python tools/ab_probe.py "resident=0" "resident=1" > $O/ab2048.txt 2>&1; cat $O/ab2048.txt
 N=1024 REPS=3 STEPS=200 timeout -k 10 300 python tools/ab_probe.py "resident=0" "resident=1" > $O/ab1024.txt 2>&1; cat $O/ab1024.txt
 N=512 REPS=3 STEPS=200 timeout -k 10 300 python tools/ab_probe.py "resident=0" "resident=1" > $O/ab512.txt 2>&1; cat $O/ab512.txt
+V=chan_vese_amd/csrc/variants; D=chan_vese_amd/csrc/libchanvese_hip.so
+[ -f $V/res16/libchanvese_hip.so ] && { N=2048 REPS=3 STEPS=200 OPTS=resident=1 timeout -k 10 300 python tools/ab_libs.py $D $V/res16/libchanvese_hip.so > $O/ab_res16.txt 2>&1; cat $O/ab_res16.txt; }
