@@ -40,8 +40,8 @@ constexpr int RT_PITCH = 132;             // doubles per LDS row: tile columns -
 #endif
 constexpr int RT_WAVES = CVH_RT_WAVES, RT_THREADS = 64 * RT_WAVES;
 constexpr int RT_HALO = 6 * RT_W;         // doubles a tile publishes per iteration: bottom 2 rows, top row, right 2 columns, left column
-constexpr int kWordStride = 16;           // one synchronisation word per 64 bytes
-constexpr unsigned kAbort = 0xffffffffu;
+
+
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 struct ResSmem {
@@ -143,7 +143,9 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   const int h = a.h, w = a.w;
   CvhResident *const rs = a.resident;
   if (*(const_int_p)&a.st->stopped != 0) return;    // sticky flag of an EARLIER launch: the same for every workgroup
-  const int t_first = *(const_int_p)&a.st->steps_done;   // iterations booked before this launch (written before it began)
+  // index of this launch's first iteration inside the run: a launch ARGUMENT (the host's count of the iterations it has enqueued since
+  // the run counter was reset), not read from the state block: a stale cached copy of that word would shift every trace row
+  const int t_first = a.res_t0;
 
   // ---- this workgroup's tile
   const int tr = a.tiles_y, tc = a.tiles_x, ntiles = tr * tc;
@@ -198,7 +200,6 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   const int rb0 = (TH * wave) / RT_WAVES, rb1 = (TH * (wave + 1)) / RT_WAVES;
   const int ca = 2 * lane;                                  // tile column of pixel a
   const bool lane_valid = ca < TWv;
-  const double vmask = lane_valid ? 1.0 : 0.0;
   const double fxa = (c0 + ca <= 0) ? 0.0 : 1.0;            // kappa_x(i, 0) = 0 (src/main.cpp:371)
   double *const halo_mine[2] = {a.res_halo + (size_t)bid * RT_HALO, a.res_halo + ((size_t)ntiles + bid) * RT_HALO};
   auto norm = [&](double fwd, double bwd, double c) -> double { return normalised4(fwd, bwd, c + c); };
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   int executed = 0;
   bool gave_up = false;
   const int nit = a.res_steps;
+  if (bid == 0 && tid == 0) { rs->pad[0] = (unsigned)t_first; rs->pad[1] = (unsigned)nit; rs->pad[2] = (unsigned)a.st->steps_done; }   // (diagnostic record of the launch)
   for (int it = 0; it < nit; ++it) {
     const int phase = (a.chain_phase + it) & 3;
     // ---- the release behind iteration it - 1: leave bit and the region means of u(it); the halos were fetched while waiting
@@ -268,15 +270,13 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       double2_t keep[4];
       int smp_keep[4];
       unsigned long long near_mask[4];
+      // (no branch inside a row: a group of four rows is one basic block and hipcc overlaps the rows' dependent chains)
       auto row = [&](int i, int k) {
         const bool lastrow = i + 1 >= rb1;                      // wave-uniform
-        double2_t up;
-        double uw_n = 0.0, ue_n = 0.0;
-        if (lastrow) up = ubot;                                 // the band below may have rewritten its first row already
-        else {
-          up = *reinterpret_cast<const double2_t *>(S(i + 1, ca));
-          uw_n = *S(i + 1, ca - 1); ue_n = *S(i + 1, ca + 2);
-        }
+        const double2_t up_l = *reinterpret_cast<const double2_t *>(S(i + 1, ca));
+        const double uw_n = *S(i + 1, ca - 1), ue_n = *S(i + 1, ca + 2);   // (unused behind the band's last row)
+        // below the band's last row: the copy taken before the march -- the band below may have rewritten its first row already
+        const double2_t up = double2_t{lastrow ? ubot.x : up_l.x, lastrow ? ubot.y : up_l.y};
         const int smp = (int)*reinterpret_cast<const unsigned short *>(simg + i * RT_W + ca);
         const int ba = smp & 0xff, bb = smp >> 8;
         const double nxl0 = snxl[i];
@@ -292,7 +292,9 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         smp_keep[k] = smp;
         const double hva = heaviside_centred_far(va, fc), hvb = heaviside_centred_far(vb, fc);
         near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
-        if (lane_valid) *reinterpret_cast<double2_t *>(S(i, ca)) = keep[k];   // in place: every reader of the old row i has it in registers
+        // in place: every reader of the old row i has it in registers.  Lanes beyond a ragged tile's width write cells nobody owns
+        // (the halo column among them: it was read a row ahead and is refreshed before the next iteration)
+        *reinterpret_cast<double2_t *>(S(i, ca)) = keep[k];
         acc[0] += hva; acc[0] += hvb;
         acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
         acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       }
       for (; i < rb1; ++i) { row(i, 0); correct(0); }
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;   // exact: lanes beyond the image contribute nothing
+      for (int s = 0; s < NS; ++s) acc[s] = lane_valid ? acc[s] : 0.0;   // lanes beyond the image contribute nothing
     }
     stamp(it, kStampIt, 2);                                    // (thread 0's wave) march done
     double total[NS];

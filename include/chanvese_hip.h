@@ -98,6 +98,11 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *                    else 2; 0 from 2^28 pixels),
  *                    0 LDS tile, 1 streaming strip (w % 16 == 0), 2 wave-streaming, 3 wave-streaming with
  *                    2 pixels per lane (1 channel, w % 16 == 0, w >= 144; other shapes fall back to 2)
+ *   "resident"       -1 auto (default), 0 off, 1 on: planes whose level set fits the LDS of the chip (1 channel, FAST, even width,
+ *                    at most one 128 x 128 tile per CU: up to 2048 x 2048 on an MI355X) iterate IN LDS -- one cooperative launch per
+ *                    chunk of iterations, one workgroup per tile, a grid barrier per iteration, the stop rule inside the kernel at the
+ *                    reference's iteration (csv_resident_kernel.hip).  Auto steps aside when "kernel", "strip_rows", "strips" or
+ *                    "graph" were set (the caller asked for a per-launch flow)
  *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while ONE context's ping-pong
  *                    pair fits the Infinity Cache, <= 300 MB), 0 plain, 1 write-through; a caller that keeps several
  *                    contexts busy on one GPU should set 0
