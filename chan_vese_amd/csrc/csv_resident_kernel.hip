@@ -142,7 +142,13 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = a.h, w = a.w;
   CvhResident *const rs = a.resident;
-  if (*(const_int_p)&a.st->stopped != 0) return;    // sticky flag of an EARLIER launch: the same for every workgroup
+  // sticky stop flag of an EARLIER launch (src/main.cpp:1000): read at agent scope -- every workgroup must see the same value, and a
+  // cooperative launch is dispatched through its own queue (a cached copy of the word is not to be trusted here)
+  if (tid == 0) s_flag[0] = __hip_atomic_load(&a.st->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int stopped_before = s_flag[0];
+  __syncthreads();
+  if (stopped_before != 0) return;
   // index of this launch's first iteration inside the run: a launch ARGUMENT (the host's count of the iterations it has enqueued since
   // the run counter was reset), not read from the state block: a stale cached copy of that word would shift every trace row
   const int t_first = a.res_t0;

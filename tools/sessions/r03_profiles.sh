@@ -6,3 +6,4 @@ for cfg in C2 C3 C4 C5; do
   bash tools/profile_round.sh r03_$cfg "$args" > gpurun_out/r03_${cfg}_summary.txt 2>&1
   tail -12 gpurun_out/r03_${cfg}_summary.txt
 done
+# (C4 re-collected after resident mode became the automatic flow for planes that fit: bash tools/profile_round.sh r03_C4 "--config C4")
