@@ -328,7 +328,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(f"csv_step_{n}x{n}x{C}")
+                # the resident kernel runs a chunk of iterations per launch: its counters are recorded per ITERATION (launch total / iterations)
+                traffic = tj.get(f"csv_resident_{n}x{n}x{C}_per_iteration") if (launch or {}).get("kernel") == "csv_resident_kernel" else tj.get(f"csv_step_{n}x{n}x{C}")
                 traffic_source = tj.get("_source") if traffic is not None else None
                 if pm_info is not None and tj.get(f"pm_2steps_{n}x{n}x{C}") is not None:
                     if pm_launch is not None and int(pm_launch["steps_per_launch"]) == 2:   # the counters were taken on the 2-step kernel

@@ -33,7 +33,7 @@ import csv, sys, json, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for r in rows:
-    kn = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+    kn = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     a = acc[kn][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 d = json.load(open(sys.argv[2]))
 for kn, cs in acc.items():
@@ -54,6 +54,6 @@ try:
 except Exception as e: print("no kernel stats", e)
 d = json.load(open(o + "/pmc_summary.json"))
 for kn, cs in d.items():
-    if "wave" in kn or "pm_" in kn:
+    if "wave" in kn or "pm_" in kn or "resident" in kn:
         print(kn[:60], {k: round(v["per_launch"], 1) for k, v in cs.items()})
 PY
