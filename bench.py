@@ -8,7 +8,8 @@ Workloads (`--config`, BASELINE.json `configs`):
   C2 (default at N=1)  4096x4096, 1 channel, clean disk, checkerboard init, 500 iterations, tol 0
   C3                   4096x4096, 3 channels (per-channel lambda), 300 iterations
   C4                   2048x2048 noisy disk: Perona-Malik 1000 steps (K=30, L=0.25, T=250) timed as its
-                       own phase (`pm` object, 16 B per plane-pixel-step), then 200 CSV iterations
+                       own phase (`pm` object, 16 B per plane-pixel-step), then 200 CSV iterations (the plane fits
+                       the chip's LDS: the library runs them in its resident flow, one cooperative launch per chunk)
   C5 (default at N>1)  the per-GPU share of the 64-image batch: 8 noisy 4096x4096 images per GPU
                        (images 8r..8r+7 on rank r), interleaved on their own streams
   C4-image, C5-image   one C4 / C5 image (noise 32 at 2048^2 / noise 16 at 4096^2), CSV only

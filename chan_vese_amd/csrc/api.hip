@@ -576,8 +576,9 @@ static Geometry resolve_geometry(const cvh_context *c)
   // auto: the 2-pixel kernel from 0.6 Mpixel up (end of round 2, one context per size, 2-pixel with its cache policy chosen by
   // footprint vs 1-pixel: 3000x4000 40.3 vs 43.8 us, 4096^2 59.4 vs 64.7, 4608^2 80.5 vs 87.2, 5120^2 93.1 vs 97.2, 6144^2 133.0 vs
   // 140.7, 4320x7680 122.7 vs 123.2, 8192^2 243.3 vs 245.5)
-  // three channels: the 2-pixel flavour exists in FAST arithmetic only, on request ("kernel" = 3) until it is measured faster
-  const bool two_px_c3 = c->C == 3 && use_fast(c) && c->kernel == 3;
+  // three channels: the 2-pixel flavour exists in FAST arithmetic only; with equal strips (no class skew) it is the faster one from
+  // round 3 on (4096^2 x 3, one context, alternating: 73.3 vs 74.9 us; bench lines of one session: 72.9 / 74.3 vs 74.5 / 76.1 us)
+  const bool two_px_c3 = c->C == 3 && use_fast(c) && (c->kernel == 3 || c->kernel == -1);
   if ((c->kernel == 3 || (c->kernel == -1 && c->n >= (size_t)600000)) && (c->C == 1 || two_px_c3) && c->w % 16 == 0 && c->w >= 144 &&
       c->n < ((size_t)1 << 28)) {
     // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
@@ -885,6 +886,7 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
   // 140.6; 8192^2 forced onto this kernel, 178 rows: 244 -> 285 us): full below 46 rows, fading to none at 128.
   int cskew = c->wave_cskew;
   if (g.strip_rows > 46) cskew = g.strip_rows >= 128 ? 0 : (int)(cskew * (128.0 - g.strip_rows) / (128.0 - 46.0));
+  if (c->C == 3 && c->wave_cskew == 500) cskew = 0;   // three channels: equal strips measured best (73.3 vs 74.1 us); any other "wave_cskew" applies as given
   compute_strip_bounds(g.strip, c->h, g.tiles_x, g.tiles_y, g.strip_rows, g.nblocks, cls, cskew, c->wave_skew, b);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
   HIPCHK(c, hipMemcpy(c->d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));

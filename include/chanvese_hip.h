@@ -94,10 +94,10 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "trace"          capacity (iterations) of the per-iteration trace, 0 = off
  *   "sync_every"     iterations enqueued between host polls of the stop flag (default 32)
  *   "graph"          1 = runs of 16 steps are replayed as one hipGraph (default), 0 = plain launches
- *   "kernel"         data flow of the CSV step: -1 auto (3 where it applies -- 1 channel, width a multiple of 16 and >= 144, from 0.6 Mpixel --
- *                    else 2; 0 from 2^28 pixels),
+ *   "kernel"         data flow of the CSV step: -1 auto (3 where it applies -- width a multiple of 16 and >= 144, from 0.6 Mpixel; three
+ *                    channels in FAST arithmetic only -- else 2; 0 from 2^28 pixels),
  *                    0 LDS tile, 1 streaming strip (w % 16 == 0), 2 wave-streaming, 3 wave-streaming with
- *                    2 pixels per lane (1 channel, w % 16 == 0, w >= 144; other shapes fall back to 2)
+ *                    2 pixels per lane (w % 16 == 0, w >= 144; other shapes fall back to 2)
  *   "resident"       -1 auto (default), 0 off, 1 on: planes whose level set fits the LDS of the chip (1 channel, FAST, even width,
  *                    at most one 128 x 128 tile per CU: up to 2048 x 2048 on an MI355X) iterate IN LDS -- one cooperative launch per
  *                    chunk of iterations, one workgroup per tile, a grid barrier per iteration, the stop rule inside the kernel at the

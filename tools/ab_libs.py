@@ -6,16 +6,17 @@ sys.path.insert(0, '.')
 import numpy as np
 from chan_vese_amd import capi, synth
 n = int(os.environ.get("N", "4096")); reps = int(os.environ.get("REPS", "4")); steps = int(os.environ.get("STEPS", "112"))
-img = synth.disk(n); u0 = None
+C_ = int(os.environ.get("C", "1"))      # C=3: the 3-channel disks of config C3, per-channel lambdas
+imgs = [synth.disk(n, 180, 40), synth.disk(n, 200, 60), synth.disk(n, 60, 200)] if C_ == 3 else [synth.disk(n)]; u0 = None
 ctxs = []
 for path in sys.argv[1:]:
     capi._lib = None; capi.LIB_PATH = os.path.abspath(path)      # bind a fresh handle of this build
     L = capi.lib()
     if u0 is None: u0 = capi.checkerboard_host(n, n)
-    ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
+    ctx = capi.Context(n, n, C_, capi.make_params(tol=0.0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]) if C_ == 3 else capi.make_params(tol=0.0))
     for kv in os.environ.get("OPTS", "").split(","):     # e.g. OPTS=kernel=3,wave_cskew=400
         if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-    ctx.set_image([img]); ctx.set_levelset(u0); ctx.enqueue_steps(400); ctx.sync()
+    ctx.set_image(imgs); ctx.set_levelset(u0); ctx.enqueue_steps(400); ctx.sync()
     ctxs.append((path, ctx))
 res = np.zeros((len(ctxs), reps))
 for r in range(reps):
