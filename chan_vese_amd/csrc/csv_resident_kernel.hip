@@ -9,11 +9,14 @@
 // chunk; what crosses workgroups per iteration is
 //   * the tile's border rows / columns (the 7-point cross reaches 2 up / left, 1 down / right: 6 x 128 doubles per tile), through a
 //     double-buffered global halo buffer, written and read with sc1 (agent scope);
-//   * the fixed-point sums of chain mode (chain_device.h) and one sum u_diff^2 row per workgroup;
-//   * ONE grid barrier: an arrival counter; the last workgroup to arrive books the iteration (norm, stop rule src/main.cpp:1000,
-//     trace row), clears the sum set after next and writes one "go" word per workgroup (every workgroup polls its own word: same-address
-//     polling does not scale, tools/experiments/persist/README.md).  The stop rule therefore fires at the reference's iteration
-//     with no extra iteration computed.
+//   * ONE grid barrier with a master.  A tile ARRIVES with three 16-byte agent-scope stores into its own 64-byte line {generation, sum
+//     u_diff^2} {generation, sum H'} {generation, sum I H'} -- the last two as chain mode's fixed-point integers (chain_device.h) -- right
+//     behind its reduction, before its border stores (those get their own signal line: only the neighbours wait for them).  Workgroup
+//     0 is the master: its eight waves watch 32 arrival lines each without workgroup barriers, wave 0 adds the integers (exact,
+//     order-free: the totals the per-launch path's atomic adds produce), books the iteration (norm, stop rule src/main.cpp:1000,
+//     trace row) and RELEASES everybody with one line per workgroup that carries the leave bit and the region means of the new level
+//     set (every workgroup polls its own line: same-address polling does not scale, tools/experiments/persist/README.md).  The stop
+//     rule therefore fires at the reference's iteration with no extra iteration computed, and no atomic is issued inside the launch.
 // Every wait is a bounded poll: a workgroup that gives up raises CvhResident::error and leaves, and so does everybody waiting
 // for it -- the grid always drains; the host reports the error at the next synchronisation.
 //
@@ -53,9 +56,10 @@ struct ResSmem {
   static constexpr int off_nxl = off_atan + CVH_ATAN2_N + 1;                // RT_HMAX: normalised x-gradient of column -1
   static constexpr int off_red = off_nxl + RT_HMAX;                         // RT_WAVES x NS
   static constexpr int off_flag = off_red + RT_WAVES * NS;
-  static constexpr int doubles = off_flag + 4 + (RT_WAVES + 1) / 2 + 1;   // 3 broadcast doubles, then ints
+  static constexpr int doubles = off_flag + 4 + (RT_WAVES + 1) / 2 + 1 + RT_WAVES / 2;   // 3 broadcast doubles, 12 ints, the master's RT_WAVES ints
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
+static_assert(32 * RT_WAVES >= CVH_RESIDENT_MAX_TILES, "the master's waves watch 32 arrival lines each");
 static_assert(ResSmem::bytes <= 160 * 1024, "the tile, its halo ring and the tables must fit one CU's LDS");
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -99,6 +103,11 @@ __device__ __forceinline__ void st_line16(void *base, unsigned byte_off, unsigne
   const unsigned long long b = (unsigned long long)__double_as_longlong(d);
   __builtin_amdgcn_raw_buffer_store_b128(u32x4r_t{w0, w1, (unsigned)b, (unsigned)(b >> 32)}, make_rsrc(base, 0x7fffffffu), byte_off, 0u, 16 /* sc1 */);
 }
+__device__ __forceinline__ void st_line16_u64(void *base, unsigned byte_off, unsigned w0, unsigned w1, unsigned long long b)
+{
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4r_t{w0, w1, (unsigned)b, (unsigned)(b >> 32)}, make_rsrc(base, 0x7fffffffu), byte_off, 0u, 16 /* sc1 */);
+}
+__device__ __forceinline__ long long line16_i64(u32x4r_t v) { return (long long)(((unsigned long long)v.w << 32) | v.z); }
 __device__ __forceinline__ double line16_f64(u32x4r_t v) { return __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z)); }
 
 // Thread 0 polls this workgroup's release line until both halves carry generation >= `gen` (bounded); the workgroup meets at a
@@ -108,6 +117,8 @@ __device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int ge
   if (threadIdx.x == 0) {
     int res = -1;
     double m1 = 0.0, m2 = 0.0;
+    // (one poll in flight: two or four in flight sample the line more often but cost 0.5 / 0.7 us per iteration at 2048^2 -- the
+    // polls of 256 workgroups compete with the arrivals and the release for the same fabric)
     for (int i = 0; i < a.res_poll_cap; ++i) {
       const u32x4r_t ga = ld_line16(rs->go, (unsigned)bid * 64u), gb = ld_line16(rs->go, (unsigned)bid * 64u + 16u);
       if (ga.x == gb.x && ga.x >= (unsigned)gen && ga.x != 0xffffffffu) { res = (int)(ga.y & 1u); m1 = line16_f64(ga); m2 = line16_f64(gb); break; }
@@ -137,9 +148,11 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   double *sred = smem + L::off_red;
   double *s_bc = smem + L::off_flag;      // 4 doubles of broadcast scratch
   int *s_flag = (int *)(s_bc + 3);
+  int *s_mflag = s_flag + 12;             // master workgroup: generation each wave's share of the arrivals is complete for
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < RT_WAVES) s_mflag[tid] = 0;
   const int h = a.h, w = a.w;
   CvhResident *const rs = a.resident;
   // sticky stop flag of an EARLIER launch (src/main.cpp:1000): read at agent scope -- every workgroup must see the same value, and a
@@ -184,11 +197,10 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     const int gr = clampi(r0 + r, 0, h - 1), gc = clampi(c0 + c, 0, w - 1);
     su[q] = a.u_in[(size_t)gr * w + gc];
   }
-  // Sum sets (chain_device.h): iteration `it` of this launch reads set p0 + it and adds into p0 + it + 1.  p0 + 1 is clear by the
-  // per-launch invariant; p0 + 2 and p0 + 3 are cleared here (long before anybody adds into them: a grid barrier lies between), and from
-  // then on every barrier clears the set that was just consumed.  The invariant holds again when the launch ends.
-  if (bid == 0 && tid < 128)
-    __hip_atomic_store(&a.chain->v[(a.chain_phase + 2 + (tid >> 6)) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Sum sets (chain_device.h): the launch reads set p0 (the sums of the level set it starts from) and leaves set p0 + executed filled and
+  // set p0 + executed + 1 clear -- the per-launch invariant -- when it ends.  In between the sums do not touch the sets: every tile hands
+  // its fixed-point integers to the master with its arrival line, and the master adds them (integer addition: exact, order-free, the
+  // very totals the per-launch path's atomic adds produce).
   // region means of the level set the launch starts from (later iterations get theirs with the release)
   double c1, c2;
   {
@@ -336,17 +348,16 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     executed = it + 1;
     const unsigned gen = (unsigned)(it + 1);
 
-    // ---- publish: fixed-point sums for the next iteration's means, the tile's border for the neighbours; then ONE 16-byte line
-    // {generation, sum u_diff^2}: the arrival (distinct addresses: 256 arrivals on one counter serialise for 6 us)
-    {
-      long long *const set = &a.chain->v[(phase + 1) & 3][0];
-      const int shard = bid % chain_shards<1>();
-      if (tid == 0)
-        __hip_atomic_fetch_add(&set[shard], __double2ll_rn(total[0] * a.chain_scale[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 64)
-        __hip_atomic_fetch_add(&set[chain_shards<1>() + shard], __double2ll_rn(total[2] * a.chain_scale[1]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+    // ---- arrive: three 16-byte lines {generation, payload}: sum u_diff^2, and the fixed-point sums the next iteration's means come from
+    // (distinct addresses: 256 arrivals on one counter serialise for 6 us).  The arrival does not wait for the border stores below: the
+    // master needs the sums only, the neighbours get their own signal.
+    if (tid < 3) {
+      const unsigned long long payload = tid == 0 ? (unsigned long long)__double_as_longlong(total[4])
+                                       : tid == 1 ? (unsigned long long)__double2ll_rn(total[0] * a.chain_scale[0])
+                                                  : (unsigned long long)__double2ll_rn(total[2] * a.chain_scale[1]);
+      st_line16_u64(rs->flag, (unsigned)bid * 64u + 16u * (unsigned)tid, gen, 0u, payload);
     }
+    // ---- the tile's border for the neighbours, then the border signal
     {
       double *const hb = halo_mine[it & 1];
       for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
@@ -361,72 +372,95 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stamp(it, kStampIt, 4);                                    // sums and borders have reached memory
-    if (tid == 0) st_line16(rs->flag, (unsigned)bid * 64u, gen, 0u, total[4]);
+    stamp(it, kStampIt, 4);                                    // borders have reached memory
+    if (tid == 0) st_line16_u64(rs->hflag, (unsigned)bid * 64u, gen, 0u, 0ull);
 
-    // ---- workgroup 0 is the barrier's master: it watches the arrival lines, books the iteration and releases everybody
+    // ---- workgroup 0 is the barrier's master.  Its eight waves watch 32 arrival lines each (lanes 0-31: the norm and sum-H' pieces,
+    // lanes 32-63: the sum-I H' piece) WITHOUT workgroup barriers: a wave whose share is complete leaves its partial sums and the
+    // generation in LDS and goes on; wave 0 collects the eight, books the iteration and releases everybody.  (Single-wave code is
+    // latency-bound -- 8 cycles an instruction: everything here is the critical path of 255 waiting workgroups.)
     if (bid == 0) {
-      double s4 = 0.0;
-      bool mine_ok = true;
-      int ok_all = 0;
+      const int b = wave * 32 + (lane & 31);                    // (host: ntiles <= 32 * RT_WAVES)
+      const bool have = b < ntiles;
+      bool done = false;
+      u32x4r_t fa = {0u, 0u, 0u, 0u}, fb = {0u, 0u, 0u, 0u};
       for (int round = 0; round < a.res_poll_cap; ++round) {
-        bool ok = true;
-        double part = 0.0;
-        for (int b = tid; b < ntiles; b += RT_THREADS) {         // fixed order per thread: b ascending
-          const u32x4r_t f = ld_line16(rs->flag, (unsigned)b * 64u);
-          ok = ok && (f.x >= gen) && (f.x != 0xffffffffu);
-          part += line16_f64(f);
+        if (have) {
+          fa = ld_line16(rs->flag, (unsigned)b * 64u + (lane < 32 ? 0u : 32u));
+          if (lane < 32) fb = ld_line16(rs->flag, (unsigned)b * 64u + 16u);
         }
-        mine_ok = ok; s4 = part;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
-        if (lane == 0) s_flag[wave] = (bal == ~0ull) ? 1 : 0;     // (s_flag: ints behind the broadcast doubles; RT_WAVES <= 16 fit)
-        __syncthreads();
-        int all = 1;
-#pragma unroll
-        for (int wv = 0; wv < RT_WAVES; ++wv) all &= s_flag[wv];
-        __syncthreads();
-        if (all) { ok_all = 1; break; }
+        const bool ok = !have || (fa.x >= gen && fa.x != 0xffffffffu && (lane >= 32 || (fb.x >= gen && fb.x != 0xffffffffu)));
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { done = true; break; }
         if ((round & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
       }
-      (void)mine_ok;
-      if (!ok_all) { if (tid == 0) st_agent(&rs->error, 1); gave_up = true; break; }
-      if (a.dbg_times && it == kStampIt && tid == 0) a.dbg_times[5] = __builtin_amdgcn_s_memrealtime();   // master: everybody has arrived
-      // iteration `it` is complete everywhere: norm (fixed order), stop rule (src/main.cpp:993-1000), region means of u(it + 1)
-      const long long entry_n = __hip_atomic_load(&a.chain->v[(phase + 1) & 3][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      double nacc[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) nacc[s] = 0;
-      nacc[0] = s4;
-      double ntot[NS];
-      block_reduce8<NS>(nacc, sred, ntot);
-      const double nrm = sqrt(ntot[0]);
-      const int stop_now = nrm <= a.stop_cond;          // :1000, after the update (the same value in every thread)
-      double n1[1], n2[1];
-      chain_means<1>(a, entry_n, n1, n2);
-      const unsigned leave = (stop_now || it + 1 >= nit) ? 1u : 0u;
-      stamp(it, kStampIt, 6);                                  // master: norm and means known
-      for (int i = tid; i < ntiles; i += RT_THREADS) {
-        st_line16(rs->go, (unsigned)i * 64u, gen, leave, n1[0]);
-        st_line16(rs->go, (unsigned)i * 64u + 16u, gen, leave, n2[0]);
-      }
-      stamp(it, kStampIt, 7);                                  // master: release issued
-      // everything else the master books comes AFTER the release (off the critical path of the other workgroups)
-      // the set everybody consumed in this iteration is the add target three iterations on: cleared now, two barriers ahead
-      if (tid >= 64 && tid < 128) __hip_atomic_store(&a.chain->v[phase][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 0) {
-        CvhState *st = a.st;
-        const int t = t_first + it;
-        if (a.trace && t < a.trace_cap) { a.trace[(size_t)t * 3] = c1; a.trace[(size_t)t * 3 + 1] = c2; a.trace[(size_t)t * 3 + 2] = nrm; }
-        st->norm = nrm;
-        st->steps_done = t + 1;
-        st->pending = 0;
-        if (stop_now) st->stopped = 1;
-        if (a.host_status) {
-          __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (done) {
+        const double ws = wave_sum((have && lane < 32) ? line16_f64(fa) : 0.0);                       // fixed order: lane = tile
+        const long long r = row16_sum_i64(!have ? 0ll : lane < 32 ? line16_i64(fb) : line16_i64(fa));
+        const long long w0 = read_lane_i64(r, 0) + read_lane_i64(r, 16), w1 = read_lane_i64(r, 32) + read_lane_i64(r, 48);
+        if (lane == 0) {
+          sred[wave * NS] = ws;
+          reinterpret_cast<long long *>(sred)[wave * NS + 1] = w0;
+          reinterpret_cast<long long *>(sred)[wave * NS + 2] = w1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(&s_mflag[wave], (int)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+      } else if (lane == 0) st_agent(&rs->error, 1);
+      if (wave == 0 && done) {
+        bool all = false;
+        for (int round = 0; round < a.res_poll_cap; ++round) {
+          const int f = lane < RT_WAVES ? __hip_atomic_load(&s_mflag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (int)gen;
+          if (__builtin_amdgcn_ballot_w64(f != (int)gen) == 0ull) { all = true; break; }
+          if ((round & 63) == 63 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (all) {
+          if (a.dbg_times && it == kStampIt && tid == 0) a.dbg_times[5] = __builtin_amdgcn_s_memrealtime();   // master: everybody has arrived
+          // iteration `it` is complete everywhere: norm (fixed order), stop rule (src/main.cpp:993-1000), region means of u(it + 1) from
+          // the integer totals
+          const double *vred = sred;                               // (plain LDS reads: the acquire fence above orders them)
+          const long long *vredq = reinterpret_cast<const long long *>(sred);
+          double s4 = vred[0];
+          long long q0 = vredq[1], q1 = vredq[2];
+#pragma unroll
+          for (int wv = 1; wv < RT_WAVES; ++wv) { s4 += vred[wv * NS]; q0 += vredq[wv * NS + 1]; q1 += vredq[wv * NS + 2]; }   // fixed order
+          const double nrm = sqrt(s4);
+          const int stop_now = nrm <= a.stop_cond;          // :1000, after the update
+          // chain_means' formula (chain_device.h) on the totals
+          const double sh = __builtin_fma((double)q0, a.chain_inv[0], 0.5 * a.npix);
+          const double sih = __builtin_fma((double)q1, a.chain_inv[1], 0.5 * a.sum_img[0]);
+          const double n1 = sih / sh, n2 = (a.sum_img[0] - sih) / (a.npix - sh);
+          const unsigned leave = (stop_now || it + 1 >= nit) ? 1u : 0u;
+          stamp(it, kStampIt, 6);                                  // master: norm and means known
+          for (int i = lane; i < ntiles; i += 64) {
+            st_line16(rs->go, (unsigned)i * 64u, gen, leave, n1);
+            st_line16(rs->go, (unsigned)i * 64u + 16u, gen, leave, n2);
+          }
+          stamp(it, kStampIt, 7);                                  // master: release issued
+          // everything else the master books comes AFTER the release (off the critical path of the other workgroups).
+          // The last iteration of the launch leaves the sums where the per-launch path expects them: set p0 + executed filled (one
+          // shard per sum), the set behind it clear
+          if (leave) {
+            __hip_atomic_store(&a.chain->v[(phase + 1) & 3][lane], lane == 0 ? q0 : lane == 32 ? q1 : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.chain->v[(phase + 2) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (tid == 0) {
+            CvhState *st = a.st;
+            const int t = t_first + it;
+            if (a.trace && t < a.trace_cap) { a.trace[(size_t)t * 3] = c1; a.trace[(size_t)t * 3 + 1] = c2; a.trace[(size_t)t * 3 + 2] = nrm; }
+            st->norm = nrm;
+            st->steps_done = t + 1;
+            st->pending = 0;
+            if (stop_now) st->stopped = 1;
+            if (a.host_status) {
+              __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
+        } else if (lane == 0) st_agent(&rs->error, 1);
       }
+      // (a master that gave up has raised the error word and released nobody: every wait below and in the other workgroups sees the
+      // word and leaves)
     }
 
     // ---- while the barrier completes: the neighbours' borders of u(it + 1) (they exist as soon as the up-to-four neighbours have
@@ -438,7 +472,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         bool sat = nb < 0;
         int ok = 0;
         for (int i = 0; i < a.res_poll_cap; ++i) {
-          if (!sat) { const u32x4r_t f = ld_line16(rs->flag, (unsigned)(nb < 0 ? 0 : nb) * 64u); sat = f.x >= gen && f.x != 0xffffffffu; }
+          if (!sat) { const u32x4r_t f = ld_line16(rs->hflag, (unsigned)(nb < 0 ? 0 : nb) * 64u); sat = f.x >= gen && f.x != 0xffffffffu; }
           if (__builtin_amdgcn_ballot_w64(!sat) == 0ull) { ok = 1; break; }
           if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
           __builtin_amdgcn_s_sleep(2);

@@ -43,16 +43,20 @@ constexpr int CVH_CHAIN_SETS = 4;
 struct CvhChainAcc { long long v[CVH_CHAIN_SETS][64]; };
 
 // Resident kernel (csv_resident_kernel.hip): the words its workgroups synchronise on, zeroed before every launch.
-constexpr int CVH_RESIDENT_MAX_TILES = 1024;
+constexpr int CVH_RESIDENT_MAX_TILES = 256;     // the master's eight waves watch 32 arrival lines each (one tile per CU: 256 on MI355X)
 struct CvhResident {
   int error;            // a bounded wait gave up (a workgroup was not resident, or a fault): the launch drains, the host reports it
   unsigned pad[15];
-  // one 64-byte line per tile, written as ONE 16-byte agent-scope store {generation, 0, sum u_diff^2 of the tile}: the tile has finished
-  // iteration generation - 1 of the launch and its borders and sums are in memory (arrivals on distinct addresses do not serialise)
+  // one 64-byte line per tile, written as THREE 16-byte agent-scope stores {generation, 0, payload}: sum u_diff^2 of the tile (double),
+  // then its fixed-point sums of H - 1/2 and I (H - 1/2) (chain_device.h's integers): the tile has finished iteration generation - 1 of
+  // the launch.  The master adds the integers itself (exact, order-free): no atomics inside the launch, and the arrival does not wait for
+  // the border stores (arrivals on distinct addresses do not serialise)
   unsigned flag[CVH_RESIDENT_MAX_TILES * 16];
   // one 64-byte line per tile, written by the master as two 16-byte stores {generation, leave, c1} {generation, leave, c2}: the release
   // behind iteration generation - 1 and the region means of the level set it produced
   unsigned go[CVH_RESIDENT_MAX_TILES * 16];
+  // one 64-byte line per tile {generation}: the tile's borders of iteration generation - 1 have reached memory (its neighbours wait for this)
+  unsigned hflag[CVH_RESIDENT_MAX_TILES * 16];
 };
 
 // Sums carried per workgroup and reduced in a fixed order (deterministic):

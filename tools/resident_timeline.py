@@ -22,7 +22,7 @@ L.cvh_debug_read(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size, C.
 w = buf[:nt * 12].reshape(nt, 12).astype(np.int64)
 t0 = w[:, 0].min()
 us = lambda x: (x - t0) / 100.0
-names = ["released into it 3", "table in LDS, band borders read", "march done (wave 0)", "all waves done, sums reduced", "sums + borders in memory",
+names = ["released into it 3", "table in LDS, band borders read", "march done (wave 0)", "all waves done, sums reduced (arrival lines stored here)", "borders in memory (border signal stored here)",
          "master: everybody has arrived", "master: norm and means known", "master: release issued", "released into it 4"]
 print("tiles", nt, info)
 for k, nm in enumerate(names):
@@ -31,7 +31,7 @@ for k, nm in enumerate(names):
     v = us(col[ok])
     print("%-34s n %4d  min %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (nm, ok.sum(), v.min(), np.median(v), np.percentile(v, 90), v.max()))
 d = lambda a_, b_: np.median((w[:, b_] - w[:, a_]) / 100.0)
-print("per workgroup (median): set-up %.2f | march (wave 0) %.2f | other waves + reduce %.2f | publish (stores complete) %.2f us" % (d(0, 1), d(1, 2), d(2, 3), d(3, 4)))
-print("last tile's stores complete %.2f -> master sees all arrivals %.2f -> norm / means %.2f -> release issued %.2f -> seen by the others: p50 %.2f max %.2f ; iteration period (p50) %.2f us" % (
-    us(w[:, 4]).max(), us(w[0, 5]), us(w[0, 6]), us(w[0, 7]), np.median(us(w[:, 8])), us(w[:, 8]).max(), np.median((w[:, 8] - w[:, 0]) / 100.0)))
+print("per workgroup (median): set-up %.2f | march (wave 0) %.2f | other waves + reduce %.2f | border stores complete %.2f us" % (d(0, 1), d(1, 2), d(2, 3), d(3, 4)))
+print("last tile's arrival stored %.2f -> master sees all arrivals %.2f -> norm / means %.2f -> release issued %.2f -> seen by the others: p50 %.2f max %.2f ; iteration period (p50) %.2f us" % (
+    us(w[:, 3]).max(), us(w[0, 5]), us(w[0, 6]), us(w[0, 7]), np.median(us(w[:, 8])), us(w[:, 8]).max(), np.median((w[:, 8] - w[:, 0]) / 100.0)))
 ctx.close()
