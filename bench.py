@@ -332,10 +332,13 @@ def main():
                 # the resident kernel runs a chunk of iterations per launch: its counters are recorded per ITERATION (launch total / iterations)
                 traffic = tj.get(f"csv_resident_{n}x{n}x{C}_per_iteration") if (launch or {}).get("kernel") == "csv_resident_kernel" else tj.get(f"csv_step_{n}x{n}x{C}")
                 traffic_source = tj.get("_source") if traffic is not None else None
-                if pm_info is not None and tj.get(f"pm_2steps_{n}x{n}x{C}") is not None:
-                    if pm_launch is not None and int(pm_launch["steps_per_launch"]) == 2:   # the counters were taken on the 2-step kernel
+                if pm_info is not None and pm_launch is not None:
+                    if pm_launch["kernel"].startswith("pm_resident_kernel"):      # one launch for all steps: counters recorded per STEP
+                        pm_info["roofline"]["traffic"] = tj.get(f"pm_resident_{n}x{n}x{C}_per_step")
+                    elif int(pm_launch["steps_per_launch"]) == 2 and tj.get(f"pm_2steps_{n}x{n}x{C}") is not None:
                         pm_info["roofline"]["traffic"] = tj[f"pm_2steps_{n}x{n}x{C}"] / 2.0   # per time step (a launch makes two)
-                    pm_info["roofline"]["traffic_source"] = tj.get("_source")
+                    if pm_info["roofline"]["traffic"] is not None:
+                        pm_info["roofline"]["traffic_source"] = tj.get("_source")
             except Exception:
                 traffic = None
         kernel_name = launch["kernel"] if not dry else "none (dry run)"     # what the library says it launches (cvh_launch_info)

@@ -61,6 +61,7 @@ struct cvh_context {
   CvhResident *d_resident = nullptr;
   double *d_res_halo = nullptr;
   int *h_resident = nullptr;     // pinned: {arrive, error} of the last launch
+  int pm_resident_cap = -1;      // workgroups of pm_resident_kernel the device holds at once (-1: not asked yet)
   int resident_opt = -1;         // option "resident": -1 auto (on where it applies, unless a per-launch knob was set), 0 off, 1 on where it applies
   int resident_cap = -1;         // workgroups the device holds at once (-1: not asked yet, 0: unavailable)
   bool resident_used = false;    // a resident launch since the last sync: its error word is checked there
@@ -312,7 +313,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
     c->kernel = (int)value;
   } else if (!strcmp(key, "pm_kernel")) {
-    if (value < -1 || value > 3) return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave), 2 (wave, 2 pixels per lane) or 3 (wave, 2 time steps per launch)");
+    if (value < -1 || value > 4)
+      return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave), 2 (wave, 2 pixels per lane), 3 (wave, 2 time steps per launch) or 4 (resident plane)");
     c->pm_kernel = (int)value;
   } else if (!strcmp(key, "pm_strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
@@ -667,7 +669,22 @@ static bool use_chain(const cvh_context *c, const Geometry &g)
 // Resident mode (csv_resident_kernel.hip): the plane is cut into tr x tc tiles of <= 128 x 128 pixels, one workgroup per tile, all
 // co-resident (one per CU), the level set stays in LDS for a chunk of iterations.  Applies to 1 channel, FAST arithmetic, chain-mode
 // sums, even widths, and planes that fit: tiles <= what the device holds, every tile 16 .. 128 rows.
-struct ResidentGeom { int tr, tc; };
+struct ResidentGeom { int tr, tc, band; };
+// tiles_y x tiles_x tiles of <= 128 rows x 128 columns, at most one per CU
+static bool resident_tiles(const cvh_context *c, int cap_blocks, ResidentGeom *rg)
+{
+  const int tw = cvh_resident_tile_w(), thmax = cvh_resident_tile_hmax();
+  const int tc = (c->w + tw - 1) / tw;
+  int cap = cap_blocks < CVH_RESIDENT_MAX_TILES ? cap_blocks : CVH_RESIDENT_MAX_TILES;
+  if (cap > c->num_cus) cap = c->num_cus;                      // one workgroup per CU: a second one on a CU would wait for its slot
+  int tr = cap / tc;
+  if (tr < 1) return false;
+  if (tr > c->h / 16) tr = c->h / 16;                          // tiles of >= 16 rows (every wave's band >= 2 rows)
+  if ((c->h + tr - 1) / tr > thmax) return false;              // does not fit the LDS of the CUs
+  rg->tr = tr; rg->tc = tc; rg->band = 0;
+  return true;
+}
+
 static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
 {
   if (!c->resident_opt || c->C != 1 || !use_fast(c) || !c->chain_opt || c->finalize_mode != 0 || (c->w & 1) || c->w < 16 || c->h < 16) return false;
@@ -683,16 +700,34 @@ static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
       c->resident_cap = cvh_resident_blocks_per_cu() * c->num_cus;
   }
   if (c->resident_cap <= 0) return false;
-  const int tw = cvh_resident_tile_w(), thmax = cvh_resident_tile_hmax();
-  const int tc = (c->w + tw - 1) / tw;
-  int cap = c->resident_cap < CVH_RESIDENT_MAX_TILES ? c->resident_cap : CVH_RESIDENT_MAX_TILES;
-  if (cap > c->num_cus) cap = c->num_cus;                      // one workgroup per CU: a second one on a CU would wait for its slot
-  int tr = cap / tc;
-  if (tr < 1) return false;
-  if (tr > c->h / 16) tr = c->h / 16;                          // tiles of >= 16 rows (every wave's band >= 2 rows)
-  if ((c->h + tr - 1) / tr > thmax) return false;              // does not fit the LDS of the CUs
-  rg->tr = tr; rg->tc = tc;
-  return true;
+  return resident_tiles(c, c->resident_cap, rg);
+}
+
+// Perona-Malik on a resident plane (pm_resident_kernel.hip): any channel count (the planes are smoothed one after the other), both
+// arithmetic flavours; the same tiles as the CSV kernel.
+static bool pm_resident_geometry(cvh_context *c, ResidentGeom *rg)
+{
+  if ((c->w & 1) || c->w < 16 || c->h < 16) return false;
+  if (c->pm_resident_cap < 0) {
+    int coop = 0;
+    c->pm_resident_cap = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && coop)
+      c->pm_resident_cap = cvh_pm_resident_blocks_per_cu() * c->num_cus;
+  }
+  if (c->pm_resident_cap <= 0) return false;
+  int cap = c->pm_resident_cap < CVH_RESIDENT_MAX_TILES ? c->pm_resident_cap : CVH_RESIDENT_MAX_TILES;
+  if (cap > c->num_cus) cap = c->num_cus;                      // one workgroup per CU
+  const int tc = (c->w + cvh_resident_tile_w() - 1) / cvh_resident_tile_w();
+  // tiles of 8 x band rows x 128 columns, every wave a band of exactly 2, 4, 8 or 16 rows: the shortest bands whose tiles the CUs hold at once
+  // (more CUs at work); the last tile row of the image may be shorter, but holds at least the two rows a border piece needs
+  for (int nr = 2; nr <= 16; nr *= 2) {
+    const int th = 8 * nr, tr = (c->h + th - 1) / th;
+    if (tr * tc > cap) continue;
+    if (c->h - (tr - 1) * th < 2) continue;
+    rg->tr = tr; rg->tc = tc; rg->band = nr;
+    return true;
+  }
+  return false;
 }
 
 // `step` = index of the launch inside the run (c->enqueued when it is enqueued): selects the chain-mode sum set
@@ -983,18 +1018,23 @@ static int warm_impl(cvh_context *c, long nsteps)
   return CVH_OK;
 }
 
+// Synchronisation words and border buffer of the resident kernels (csv_resident_kernel.hip, pm_resident_kernel.hip), pinned error word.
+static int ensure_resident_buffers(cvh_context *c)
+{
+  if (c->d_resident) return CVH_OK;
+  const int halo = cvh_resident_halo_doubles() > cvh_pm_resident_halo_doubles() ? cvh_resident_halo_doubles() : cvh_pm_resident_halo_doubles();
+  HIPCHK(c, hipMalloc((void **)&c->d_resident, sizeof(CvhResident)));
+  HIPCHK(c, hipMalloc((void **)&c->d_res_halo, (size_t)2 * CVH_RESIDENT_MAX_TILES * halo * sizeof(double)));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_resident, 64, hipHostMallocDefault));
+  memset(c->h_resident, 0, 64);
+  return CVH_OK;
+}
+
 // One cooperative launch per chunk of iterations (csv_resident_kernel.hip).
 static int launch_resident(cvh_context *c, const ResidentGeom &rg, int nsteps, CvhLaunchNote *note)
 {
   const int ntiles = rg.tr * rg.tc;
-  if (!note) {
-    if (!c->d_resident) {
-      HIPCHK(c, hipMalloc((void **)&c->d_resident, sizeof(CvhResident)));
-      HIPCHK(c, hipMalloc((void **)&c->d_res_halo, (size_t)2 * CVH_RESIDENT_MAX_TILES * cvh_resident_halo_doubles() * sizeof(double)));
-      HIPCHK(c, hipHostMalloc((void **)&c->h_resident, 64, hipHostMallocDefault));
-      memset(c->h_resident, 0, 64);
-    }
-  }
+  if (!note) { const int rc = ensure_resident_buffers(c); if (rc != CVH_OK) return rc; }
   constexpr int kMaxPerLaunch = 4096;
   for (int s = 0; s < nsteps || note;) {
     const int n = nsteps - s < kMaxPerLaunch ? nsteps - s : kMaxPerLaunch;
@@ -1266,6 +1306,59 @@ extern "C" int cvh_pm_trip_count(double L, double T)
   return n;
 }
 
+// "pm_kernel" = -1: the resident kernel pays ~25 us per cooperative launch that the per-launch flow does not, and gains 0.9 us per step
+// on small planes, 1.6 at 1024^2, 4 at 2048^2 (tools/pm_flows.py): runs shorter than this keep the per-launch flow
+static int pm_resident_min_trips(size_t n) { return n >= ((size_t)3 << 20) ? 8 : (n >= ((size_t)1 << 20) ? 16 : 32); }
+
+// Perona-Malik with the plane resident in LDS: per channel uint8 -> FP64 plane, ONE cooperative launch per chunk of time steps,
+// FP64 -> uint8 (round-half-even, :551) behind the last step.
+static int pm_run_resident(cvh_context *c, const CvhPmArgs &base, const ResidentGeom &rg, int trips)
+{
+  { const int rc = ensure_resident_buffers(c); if (rc != CVH_OK) return rc; }
+  CvhPmArgs a = base;
+  a.tiles_x = rg.tc; a.tiles_y = rg.tr; a.res_band_rows = rg.band;
+  a.resident = c->d_resident;
+  a.res_halo = c->d_res_halo;
+  a.res_poll_cap = 2000000;
+  a.dbg_times = c->d_dbg;
+  constexpr int kMaxPerLaunch = 1 << 16;
+  {
+    CvhLaunchNote nb{};
+    CvhPmArgs pa = a; pa.note = &nb; pa.res_steps = trips;
+    (void)cvh_launch_pm_resident(pa, c->stream);
+    snprintf(c->pm_desc, sizeof(c->pm_desc), "kernel=%s grid=%u block=%u lds_bytes=%u steps_per_launch=%d tiles_y=%d tiles_x=%d launches=%d graph_launches=0 trips=%d planes=%d",
+             nb.name, nb.grid, nb.block, nb.lds, trips < kMaxPerLaunch ? trips : kMaxPerLaunch, rg.tr, rg.tc, (trips + kMaxPerLaunch - 1) / kMaxPerLaunch, trips, c->C);
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_resident, 0, sizeof(CvhResident), c->stream));
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int k = 0; k < c->C; ++k) {
+    HIPCHK(c, cvh_launch_pm_load(c->d_img[k], c->d_pm[0], c->n, c->stream));
+    int cur = 0;
+    for (int t = 0; t < trips;) {
+      const int n = trips - t < kMaxPerLaunch ? trips - t : kMaxPerLaunch;
+      // the border signals count the steps of ONE launch; the error word stays up across the launches of this call
+      HIPCHK(c, hipMemsetAsync(c->d_resident->hflag, 0, sizeof(c->d_resident->hflag), c->stream));
+      CvhPmArgs pa = a;
+      pa.in = c->d_pm[cur]; pa.out = c->d_pm[cur ^ 1]; pa.res_steps = n;
+      HIPCHK(c, cvh_launch_pm_resident(pa, c->stream));
+      cur ^= 1;
+      t += n;
+    }
+    HIPCHK(c, cvh_launch_pm_store(c->d_pm[cur], c->d_img[k], c->n, c->stream));
+  }
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_resident, c->d_resident, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventElapsedTime(&c->last_pm_ms, c->ev0, c->ev1));
+  c->stop_valid = false;
+  c->sums_valid = false;
+  if (c->h_resident[0]) {
+    c->h_resident[0] = 0;
+    return fail(c, CVH_ERR_HIP, "cvh_perona_malik: a wait of the resident kernel gave up (a workgroup was not resident, or a fault); the planes are undefined");
+  }
+  return CVH_OK;
+}
+
 extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
 {
   if (!c) return CVH_ERR_ARG;
@@ -1285,6 +1378,15 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   a.h = c->h; a.w = c->w; a.K2 = K * K; a.L = L;
   a.invK2 = 1.0 / (K * K); a.L4 = L / 4; a.fast = use_fast(c) ? 1 : 0;
   a.pol = (c->wave_pol >= 0 ? (c->wave_pol == 1) : ((double)c->n * 16.0 <= 300e6 ? 1 : 0));
+  // A plane whose FP64 state fits the chip's LDS stays there for the whole run (pm_resident_kernel.hip): one cooperative launch per
+  // channel, the tiles' borders cross workgroups, nothing else moves.
+  {
+    ResidentGeom rg;
+    const bool want = c->pm_kernel == 4 || (c->pm_kernel == -1 && c->pm_strip_rows == 0 && trips >= pm_resident_min_trips(c->n));
+    if (want && trips > 0 && pm_resident_geometry(c, &rg)) return pm_run_resident(c, a, rg, trips);
+    if (c->pm_kernel == 4 && trips > 0)
+      return fail(c, CVH_ERR_ARG, "pm_kernel 4 (resident plane) needs an even width, >= 16 rows and columns, and a plane that fits the LDS of the CUs");
+  }
   // auto: the 2-pixel kernel for large planes (measured 50.4 vs 53.3 us/step at 4096^2, but 19 vs 15.7 at 2048^2:
   // its strips get too short there), the 1-pixel wave kernel otherwise
   const bool pm2_ok = c->w % 2 == 0 && c->w >= 128 && c->n < ((size_t)1 << 28);

@@ -149,6 +149,13 @@ struct CvhPmArgs {
   int fast;
   int strip_rows;    // wave kernel: rows per wave
   int pol;           // 2-step wave kernel: 1 = write-through stores (the state planes fit the Infinity Cache), 0 = plain
+  // resident kernel (pm_resident_kernel.hip): tiles_y x tiles_x tiles, one workgroup each, res_steps time steps in one launch
+  CvhResident *resident;         // border signals (hflag) and the error word
+  double *res_halo;              // 2 x tiles x 1024 doubles: the tiles' borders, double-buffered by step parity
+  int res_steps;
+  int res_band_rows;             // rows per wave: 2, 4, 8 or 16 (tiles of 8 x that many rows)
+  int res_poll_cap;              // polls before a wait gives up
+  unsigned long long *dbg_times; // diagnostic (option "debug_times", tools/pm_resident_timeline.py): 12 stamps per workgroup, or null
   CvhLaunchNote *note;   // host only: describe the launch instead of issuing it (CVH_LAUNCH)
 };
 
@@ -161,6 +168,10 @@ hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStr
 int cvh_wave2_cols();
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, int channels, hipStream_t s);
+size_t cvh_pm_resident_lds_bytes();
+int cvh_pm_resident_halo_doubles();
+int cvh_pm_resident_blocks_per_cu();
+hipError_t cvh_launch_pm_resident(const CvhPmArgs &a, hipStream_t s);
 size_t cvh_resident_lds_bytes();
 int cvh_resident_tile_w();
 int cvh_resident_tile_hmax();

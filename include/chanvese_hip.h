@@ -110,9 +110,13 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
  *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
  *   "dma"            tile kernel: 1 = global->LDS DMA loader (slower on MI355X, default 0)
- *   "pm_kernel"      Perona-Malik data flow: -1 auto (= 3), 0 LDS tile,
+ *   "pm_kernel"      Perona-Malik data flow: -1 auto (= 4 where the plane qualifies, else 3), 0 LDS tile,
  *                    1 wave-streaming, 2 wave-streaming with 2 pixels per lane (even w >= 128),
- *                    3 wave-streaming with TWO time steps per launch (an odd last step runs flavour 1)
+ *                    3 wave-streaming with TWO time steps per launch (an odd last step runs flavour 1),
+ *                    4 resident plane: the FP64 state of a channel stays in the LDS of the CUs for all time steps, one
+ *                    cooperative launch per channel (even width, >= 16 rows and columns, <= 128 rows x 128 columns per CU:
+ *                    up to 2048 x 2048 on MI355X; CVH_ERR_ARG if asked for a plane that does not qualify; auto steps
+ *                    aside when "pm_strip_rows" was set)
  *   "pm_strip_rows"  Perona-Malik wave kernel: rows per strip (0 auto)
  * (Ablation / diagnostic knobs of the wave kernels are not part of this interface: they are listed in
  * chan_vese_amd/csrc/cvh_internal.h.)  Unknown keys and out-of-range values return CVH_ERR_ARG. */

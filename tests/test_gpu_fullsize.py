@@ -436,16 +436,16 @@ def test_three_channel_flavours_agree_at_4096(capi):
 
 def test_pm_flavours_agree_at_2048(capi):
     """Perona-Malik data flows at 2048^2, STRICT arithmetic, 9 steps (odd: the 2-step kernel's last step runs the 1-step
-    kernel): uint8 planes identical across the tile, wave, 2-pixel wave (16-byte stores) and 2-step kernels."""
+    kernel): uint8 planes identical across the tile, wave, 2-pixel wave (16-byte stores), 2-step and resident-plane kernels."""
     n = 2048
     img = synth.config_planes("C4", n)
     outs = {}
-    for pk in (0, 1, 2, 3):
+    for pk in (0, 1, 2, 3, 4):
         with capi.Context(n, n, 1) as ctx:
             ctx.set_option("math_mode", 1)
             ctx.set_option("pm_kernel", pk)
             ctx.set_image(img)
             ctx.perona_malik(30.0, 0.25, 2.25)
             outs[pk] = ctx.get_image()[0]
-    for pk in (0, 2, 3):
+    for pk in (0, 2, 3, 4):
         assert np.array_equal(outs[pk], outs[1]), pk

@@ -134,7 +134,10 @@ def test_launch_info_names_what_runs(capi):
         assert ctx.launch_info()["kernel"].startswith("csv_step_kernel<1, 14, false, false,")
         with pytest.raises(capi.CvhError):
             ctx.launch_info(1)            # no Perona-Malik run yet
-        ctx.perona_malik(30.0, 0.25, 2.25)
+        ctx.perona_malik(30.0, 0.25, 5.0)
+        p = ctx.launch_info(1)      # the default for a plane that fits the chip's LDS and a run of >= 16 steps: one cooperative launch
+        assert p["kernel"].startswith("pm_resident_kernel<false, ") and p["launches"] == "1" and p["trips"] == "20"
+        ctx.perona_malik(30.0, 0.25, 2.25)      # a short run keeps the per-launch flow
         p = ctx.launch_info(1)
         assert p["kernel"].startswith("pm_wave_k2_kernel<false,") and p["steps_per_launch"] == "2" and p["trips"] == "9"
         assert p["last_step_kernel"].startswith("pm_wave_kernel<false>")
@@ -450,7 +453,8 @@ def test_enqueue_sync_interleaved_contexts(capi, oracle):
 
 @pytest.mark.parametrize("pm_opts", [dict(pm_kernel=2), dict(pm_kernel=2, pm_strip_rows=8), dict(pm_kernel=2, pm_strip_rows=20),
                                      dict(pm_kernel=1), dict(pm_kernel=1, pm_strip_rows=8), dict(pm_kernel=0), dict(),
-                                     dict(pm_kernel=3), dict(pm_kernel=3, pm_strip_rows=8), dict(pm_kernel=3, pm_strip_rows=24)])
+                                     dict(pm_kernel=3), dict(pm_kernel=3, pm_strip_rows=8), dict(pm_kernel=3, pm_strip_rows=24),
+                                     dict(pm_strip_rows=16)])
 @pytest.mark.parametrize("shape,K,L,T", [((40, 56), 30, 0.25, 5), ((64, 64), 10, 0.25, 20),
                                          ((37, 130), 1000, 0.1, 1.5), ((1, 50), 30, 0.25, 2),
                                          ((50, 1), 30, 0.25, 2), ((3, 3), 30, 0.2, 1),
@@ -458,7 +462,8 @@ def test_enqueue_sync_interleaved_contexts(capi, oracle):
 def test_perona_malik_parity(capi, oracle, shape, K, L, T, pm_opts):
     """Every Perona-Malik data flow (tile, wave, wave with 2 pixels per lane: even widths >= 128, one or several
     wave-columns of 124, exact and partial; wave with TWO time steps per launch: even and odd trip counts, strips
-    shorter than / equal to / longer than the image) against the oracle."""
+    shorter than / equal to / longer than the image; no option: the resident-plane kernel where the shape qualifies --
+    tests/test_gpu_pm_resident.py -- and the 2-step kernel elsewhere) against the oracle."""
     h, w = shape
     rng = np.random.default_rng(11 + h + w)
     planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]
