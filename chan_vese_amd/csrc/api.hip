@@ -60,8 +60,10 @@ struct cvh_context {
   // resident kernel (csv_resident_kernel.hip): cache-resident planes iterate in LDS, one cooperative launch per chunk
   CvhResident *d_resident = nullptr;
   double *d_res_halo = nullptr;
+  double *d_pm_halo = nullptr;   // pm_resident_kernel's border entries {value, tag}: its own buffer (tags must never meet foreign data)
   int *h_resident = nullptr;     // pinned: {arrive, error} of the last launch
   int pm_resident_cap = -1;      // workgroups of pm_resident_kernel the device holds at once (-1: not asked yet)
+  unsigned pm_res_serial = 0;    // launches of pm_resident_kernel so far (tag of the border entries; 0 = the cleared buffer)
   int resident_opt = -1;         // option "resident": -1 auto (on where it applies, unless a per-launch knob was set), 0 off, 1 on where it applies
   int resident_cap = -1;         // workgroups the device holds at once (-1: not asked yet, 0: unavailable)
   bool resident_used = false;    // a resident launch since the last sync: its error word is checked there
@@ -180,6 +182,7 @@ extern "C" void cvh_destroy(cvh_context *c)
   if (c->d_chain) (void)hipFree(c->d_chain);
   if (c->d_resident) (void)hipFree(c->d_resident);
   if (c->d_res_halo) (void)hipFree(c->d_res_halo);
+  if (c->d_pm_halo) (void)hipFree(c->d_pm_halo);
   if (c->h_resident) (void)hipHostFree(c->h_resident);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->h_status) (void)hipHostFree(c->h_status);
@@ -1022,7 +1025,7 @@ static int warm_impl(cvh_context *c, long nsteps)
 static int ensure_resident_buffers(cvh_context *c)
 {
   if (c->d_resident) return CVH_OK;
-  const int halo = cvh_resident_halo_doubles() > cvh_pm_resident_halo_doubles() ? cvh_resident_halo_doubles() : cvh_pm_resident_halo_doubles();
+  const int halo = cvh_resident_halo_doubles();
   HIPCHK(c, hipMalloc((void **)&c->d_resident, sizeof(CvhResident)));
   HIPCHK(c, hipMalloc((void **)&c->d_res_halo, (size_t)2 * CVH_RESIDENT_MAX_TILES * halo * sizeof(double)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_resident, 64, hipHostMallocDefault));
@@ -1318,7 +1321,12 @@ static int pm_run_resident(cvh_context *c, const CvhPmArgs &base, const Resident
   CvhPmArgs a = base;
   a.tiles_x = rg.tc; a.tiles_y = rg.tr; a.res_band_rows = rg.band;
   a.resident = c->d_resident;
-  a.res_halo = c->d_res_halo;
+  if (!c->d_pm_halo) {
+    const size_t bytes = (size_t)2 * CVH_RESIDENT_MAX_TILES * cvh_pm_resident_halo_doubles() * sizeof(double);
+    HIPCHK(c, hipMalloc((void **)&c->d_pm_halo, bytes));
+    HIPCHK(c, hipMemset(c->d_pm_halo, 0, bytes));            // tag 0: matches no launch
+  }
+  a.res_halo = c->d_pm_halo;
   a.res_poll_cap = 2000000;
   a.dbg_times = c->d_dbg;
   constexpr int kMaxPerLaunch = 1 << 16;
@@ -1336,10 +1344,9 @@ static int pm_run_resident(cvh_context *c, const CvhPmArgs &base, const Resident
     int cur = 0;
     for (int t = 0; t < trips;) {
       const int n = trips - t < kMaxPerLaunch ? trips - t : kMaxPerLaunch;
-      // the border signals count the steps of ONE launch; the error word stays up across the launches of this call
-      HIPCHK(c, hipMemsetAsync(c->d_resident->hflag, 0, sizeof(c->d_resident->hflag), c->stream));
       CvhPmArgs pa = a;
       pa.in = c->d_pm[cur]; pa.out = c->d_pm[cur ^ 1]; pa.res_steps = n;
+      pa.res_serial = ++c->pm_res_serial;        // border entries carry {serial, step}: nothing an earlier launch left can match
       HIPCHK(c, cvh_launch_pm_resident(pa, c->stream));
       cur ^= 1;
       t += n;

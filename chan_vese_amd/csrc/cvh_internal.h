@@ -150,8 +150,9 @@ struct CvhPmArgs {
   int strip_rows;    // wave kernel: rows per wave
   int pol;           // 2-step wave kernel: 1 = write-through stores (the state planes fit the Infinity Cache), 0 = plain
   // resident kernel (pm_resident_kernel.hip): tiles_y x tiles_x tiles, one workgroup each, res_steps time steps in one launch
-  CvhResident *resident;         // border signals (hflag) and the error word
-  double *res_halo;              // 2 x tiles x 1024 doubles: the tiles' borders, double-buffered by step parity
+  CvhResident *resident;         // the error word
+  double *res_halo;              // 2 x tiles x 1024 entries of 16 bytes {value, tag}: the tiles' borders, double-buffered by step parity
+  unsigned res_serial;           // tag of this launch (entries left by earlier launches never match)
   int res_steps;
   int res_band_rows;             // rows per wave: 2, 4, 8 or 16 (tiles of 8 x that many rows)
   int res_poll_cap;              // polls before a wait gives up

@@ -9,16 +9,21 @@
 // there is NO grid barrier: a tile waits for its up-to-eight neighbours only.
 //
 // One step of a tile:
-//   1. (steps > 0) wait until the neighbours' border signals carry the previous step, gather the halo ring from their
-//      border pieces (at the image's border: BORDER_REPLICATE = the clamped pixel, own tile or a neighbour's);
-//   2. every wave computes its band of <= 16 rows x 128 columns (lane <-> two adjacent columns) from the OLD tile and keeps the
-//      32 new values per lane in registers: g = 1 / (1 + |Sobel|^2 / K^2) (:503-520) of the own columns marches down in
-//      registers, its x-neighbours come over DPP, the two edge columns' g (tile columns -1 and TW) from a per-wave pre-pass;
-//   3. workgroup barrier, the new values replace the old tile in LDS;
-//   4. the tile's border -- top / bottom two rows, left / right two columns: a step reaches two pixels (g of a neighbour
-//      needs the neighbour's 3 x 3) -- goes into a double-buffered global buffer with agent-scope stores, then the border signal.
-// Every wait is a bounded poll: a workgroup that gives up raises CvhResident::error and leaves, and so does everybody waiting
-// for it -- the grid always drains; the host reports the error.
+//   1. (steps > 0) every thread polls its <= 3 cells of the halo ring in the neighbours' border pieces until they carry the previous
+//      step: an entry of the border buffer is 16 bytes {value, tag = (launch serial, step)}, written with ONE store, so there is no
+//      separate signal to wait for (one memory round trip instead of signal-then-data); at the image's border the cell is the
+//      clamped pixel (BORDER_REPLICATE), own tile or a neighbour's;
+//   2. every wave computes its band of NR rows x 128 columns (lane <-> two adjacent columns) from the OLD tile: the row pass of the
+//      Sobel pair (:503-504) is shared by the three rows of g that need it, g = 1 / (1 + |Sobel|^2 / K^2) (:503-520) of the own
+//      columns marches down in registers, its x-neighbours come over DPP, the two edge columns' g (tile columns -1 and TW) from a
+//      per-wave pre-pass; a row is rewritten in place as soon as it is computed, except the band's first and last two rows (the
+//      neighbouring bands still read them), which wait in registers for
+//   3. the workgroup barrier;
+//   4. the tile's border -- top / bottom two rows, left / right two columns: a step reaches two pixels (g of a neighbour needs
+//      the neighbour's 3 x 3) -- goes into a double-buffered global buffer with agent-scope 16-byte stores: from the registers while
+//      the band is computed (full tiles), from LDS behind the barrier (ragged tiles).
+// Every wait is a bounded poll: a thread that gives up raises CvhResident::error and its workgroup leaves, and so does everybody
+// waiting for it -- the grid always drains; the host reports the error.
 //
 // The arithmetic of a pixel is pm_wave_k2_kernel.hip's (hence pm_wave_kernel's) operation by operation in both flavours: STRICT
 // stays bit-exact against the oracle, FAST gives the very doubles the per-launch kernels give.
@@ -38,6 +43,10 @@ constexpr int PT_HALO = 8 * PT_W;         // doubles a tile publishes per step: 
 constexpr int PT_RING = 4 * PT_PITCH + 4 * PT_HMAX;          // cells of the halo ring (rows -2, -1, TH, TH+1; columns -2, -1, TW, TW+1)
 constexpr int PT_GATHER = (PT_RING + PT_THREADS - 1) / PT_THREADS;   // ring cells per thread
 
+#ifndef CVH_PMR_SB
+#define CVH_PMR_SB 1                      // scheduling barrier behind every (CVH_PMR_SB + 1)-th row of the march (A/B builds: 0, 3, 1023)
+#endif
+
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
 
@@ -55,6 +64,17 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte agent-scope (sc1) accesses to the border buffer: one entry {value, tag}, one transaction
+__device__ __forceinline__ u32x4s_t ld_line16(const void *base, unsigned byte_off)
+{
+  return __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, 0x7fffffffu), byte_off, 0u, 16 /* sc1 */);
+}
+__device__ __forceinline__ u32x4s_t tagged(double v, unsigned tag_lo, unsigned tag_hi)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return u32x4s_t{(unsigned)b, (unsigned)(b >> 32), tag_lo, tag_hi};
+}
 
 __device__ __forceinline__ double dpp_from_right(double v)
 {
@@ -98,6 +118,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = a.h, w = a.w;
   CvhResident *const rs = a.resident;
+  if (tid == 0) s_flag[0] = 0;                           // raised by a thread whose wait gave up (read behind the next barrier)
 
   // ---- this workgroup's tile
   const int tr = a.tiles_y, tc = a.tiles_x, ntiles = tr * tc;
@@ -156,14 +177,6 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
       }
     }
   }
-  // the up-to-eight neighbours whose signal this tile waits for (lane 0..7 of wave 0)
-  int nb_tile = -1;
-  if (tid < 8) {
-    const int k = tid < 4 ? tid : tid + 1;             // 0..8 without the centre
-    const int ny = ty + k / 3 - 1, nx = tx + k % 3 - 1;
-    if (ny >= 0 && ny < tr && nx >= 0 && nx < tc) nb_tile = ny * tc + nx;
-  }
-
   // ---- this wave's band, this lane's two columns
   const int rb0 = NR * wave;                                // (rows of the band beyond a short tile are computed from stale cells and dropped)
   const int ca = 2 * lane;                                  // tile column of pixel a (b = a + 1)
@@ -225,35 +238,38 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
   bool gave_up = false;
   for (int st = 0; st < nsteps; ++st) {
     stamp(st, kStampStep, 0); stamp(st, kStampStep + 1, 8);
-    // ---- 1. the neighbours' borders of the previous step into the halo ring
+    // ---- 1. the neighbours' borders of the previous step into the halo ring.  No signal to wait for: every entry of the border buffer
+    // carries its own tag {launch serial, step}, written with its value in ONE 16-byte store; a thread polls its <= 3 entries until they
+    // carry the step it needs (one memory round trip instead of signal-then-data).  Entries of the own tile (the image's border) are
+    // copied from LDS.
     if (st > 0) {
-      if (tid < 64) {
-        bool sat = nb_tile < 0;
-        int ok = 0;
-        for (int i = 0; i < a.res_poll_cap; ++i) {
-          if (!sat) sat = ld_agent(&rs->hflag[(size_t)nb_tile * 16]) >= (unsigned)st;
-          if (__builtin_amdgcn_ballot_w64(!sat) == 0ull) { ok = 1; break; }
-          if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-          __builtin_amdgcn_s_sleep(2);
-        }
-        if (lane == 0) { if (!ok) st_agent(&rs->error, 1); s_flag[0] = ok; }
-      }
-      __syncthreads();
-      const int okn = s_flag[0];
-      __syncthreads();
-      if (!okn) { gave_up = true; break; }
-      stamp(st, kStampStep, 1);                               // the neighbours' borders are there
-      const double *const hb = a.res_halo + (size_t)((st - 1) & 1) * ntiles * PT_HALO;
+      const unsigned char *const hb = reinterpret_cast<const unsigned char *>(a.res_halo) + (size_t)((st - 1) & 1) * ntiles * PT_HALO * 16u;
+      const unsigned want_lo = (unsigned)st, want_hi = a.res_serial;
       double v[PT_GATHER];
+      unsigned need = 0;
 #pragma unroll
-      for (int j = 0; j < PT_GATHER; ++j)
-        if (g_dst[j] >= 0 && g_src[j] >= 0) v[j] = ld_agent_f64(hb + g_src[j]);
+      for (int j = 0; j < PT_GATHER; ++j) need |= (g_dst[j] >= 0 && g_src[j] >= 0) ? (1u << j) : 0u;
+      for (int i = 0; i < a.res_poll_cap && need; ++i) {
+#pragma unroll
+        for (int j = 0; j < PT_GATHER; ++j) {
+          if (need & (1u << j)) {
+            const u32x4s_t c = ld_line16(hb, (unsigned)g_src[j] * 16u);
+            if (c.z == want_lo && c.w == want_hi) { v[j] = __longlong_as_double((long long)(((unsigned long long)c.y << 32) | c.x)); need &= ~(1u << j); }
+          }
+        }
+        if (need) {
+          if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (need) { st_agent(&rs->error, 1); s_flag[0] = 1; }     // gave up (or somebody else did): the workgroup leaves behind the barrier
 #pragma unroll
       for (int j = 0; j < PT_GATHER; ++j) {
-        if (g_dst[j] >= 0) sI[g_dst[j]] = g_src[j] >= 0 ? v[j] : sI[~g_src[j]];
+        if (g_dst[j] >= 0 && !(need & (1u << j))) sI[g_dst[j]] = g_src[j] >= 0 ? v[j] : sI[~g_src[j]];
       }
     }
     __syncthreads();
+    if (s_flag[0] != 0) { gave_up = true; break; }
     stamp(st, kStampStep, 2);                                 // halo ring in LDS
 
     // ---- 2. the band, from the old tile into registers
@@ -279,10 +295,12 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
     constexpr int NK = NR < 4 ? NR : 4;
     double2_t keep[NK];
     const bool pub_regs = TH == THN && TWv == PT_W && st + 1 < nsteps;   // the border goes out from registers
-    double *const hb_mine = a.res_halo + ((size_t)(st & 1) * ntiles + bid) * PT_HALO;
-    const __amdgpu_buffer_rsrc_t rh = make_rsrc(hb_mine, PT_HALO * 8u);
+    unsigned char *const hb_mine = reinterpret_cast<unsigned char *>(a.res_halo) + ((size_t)(st & 1) * ntiles + bid) * PT_HALO * 16u;
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(hb_mine, PT_HALO * 16u);
+    const unsigned tag_lo = (unsigned)(st + 1), tag_hi = a.res_serial;      // what the neighbours wait for before their step st + 1
     // left two columns (lane 0 -> pieces 4, 5) and right two (lane 63 -> pieces 6, 7), row by row; every other lane's store is dropped
-    const unsigned vcol = (pub_regs && (lane == 0 || lane == 63)) ? ((lane == 0 ? 4u : 6u) * PT_W + (unsigned)rb0) * 8u : kOobOffset;
+    const bool col_lane = pub_regs && (lane == 0 || lane == 63);
+    const unsigned vcol = col_lane ? ((lane == 0 ? 4u : 6u) * PT_W + (unsigned)rb0) * 16u : kOobOffset;
     {
       Row x0 = load_row(rb0), xp = load_row(rb0 + 1), xq = load_row(rb0 + 2);    // (xq: one row ahead of its use -- LDS latency)
       HRow h0, hp;
@@ -343,22 +361,25 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
         if (k < 2) keep[k] = double2_t{ox, oy};
         else if (k >= NR - 2) keep[k - (NR - NK)] = double2_t{ox, oy};
         else if (lane_valid && i < TH) *reinterpret_cast<double2_t *>(S(i, ca)) = double2_t{ox, oy};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ox), rh, vcol + (unsigned)k * 8u, 0u, 16 /* sc1 */);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, oy), rh, vcol + (unsigned)(PT_W + k) * 8u, 0u, 16);
+        if (col_lane) {      // (two active lanes: a 16-byte store of 64 lanes, 62 of them dropped for their offset, costs the memory pipe 4x a masked one)
+          __builtin_amdgcn_raw_buffer_store_b128(tagged(ox, tag_lo, tag_hi), rh, vcol + (unsigned)k * 16u, 0u, 16 /* sc1 */);
+          __builtin_amdgcn_raw_buffer_store_b128(tagged(oy, tag_lo, tag_hi), rh, vcol + (unsigned)(PT_W + k) * 16u, 0u, 16);
+        }
         x0 = xp; xp = xpp;
         h0 = hp; hp = hpp;
         g0a = gpa; g0b = gpb;
         vda = vna; vdb = vnb; gsa = gna; gsb = gnb;
-        if (k & 1) __builtin_amdgcn_sched_barrier(0);      // two rows at a time are interleaved, not more (registers)
+        if ((k & CVH_PMR_SB) == CVH_PMR_SB) __builtin_amdgcn_sched_barrier(0);      // CVH_PMR_SB + 1 rows at a time may be interleaved, not more (registers)
       }
     }
     // ---- the top / bottom two rows of a full tile straight from the registers: the stores travel while the workgroup meets
     if (pub_regs) {
-      auto st16 = [&](double2_t v, unsigned off) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s_t, v), rh, off, 0u, 16 /* sc1 */);
+      auto st_row = [&](double2_t v, unsigned piece) {
+        __builtin_amdgcn_raw_buffer_store_b128(tagged(v.x, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)ca) * 16u, 0u, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128(tagged(v.y, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)ca + 1u) * 16u, 0u, 16);
       };
-      if (rb0 == 0) { st16(keep[0], (0u * PT_W + (unsigned)ca) * 8u); st16(keep[1], (1u * PT_W + (unsigned)ca) * 8u); }
-      if (rb0 + NR == TH) { st16(keep[NK - 2], (2u * PT_W + (unsigned)ca) * 8u); st16(keep[NK - 1], (3u * PT_W + (unsigned)ca) * 8u); }
+      if (rb0 == 0) { st_row(keep[0], 0u); st_row(keep[1], 1u); }
+      if (rb0 + NR == TH) { st_row(keep[NK - 2], 2u); st_row(keep[NK - 1], 3u); }
     }
     stamp(st, kStampStep, 3);                                 // (thread 0's wave) band computed
     __syncthreads();
@@ -370,28 +391,22 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
         if ((k < 2 || k >= NR - 2) && rb0 + k < TH) *reinterpret_cast<double2_t *>(S(rb0 + k, ca)) = keep[k < 2 ? k : k - (NR - NK)];
       }
     }
-    if (pub_regs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stamp(st, kStampStep, 5);                                 // tile rewritten
-    // ---- 4. the tile's border for the neighbours (tiles that are not full: from LDS), then the border signal
-    if (st + 1 < nsteps) {
-      if (!pub_regs) {
-        for (int q = tid; q < PT_HALO; q += PT_THREADS) {
-          const int piece = q / PT_W, k = q % PT_W;
-          const int kr = k < TH ? k : TH - 1;
-          double v;
-          if (piece < 2) v = *S(piece, k);                             // top two rows
-          else if (piece < 4) v = *S(TH - 4 + piece, k);               // bottom two rows: TH - 2, TH - 1
-          else if (piece < 6) v = *S(kr, piece - 4);                   // left two columns
-          else v = *S(kr, TWv - 8 + piece);                            // right two columns: TWv - 2, TWv - 1
-          st_agent_f64(hb_mine + q, v);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    // ---- 4. the border of a tile that is not full: from LDS
+    if (st + 1 < nsteps && !pub_regs) {
+      for (int q = tid; q < PT_HALO; q += PT_THREADS) {
+        const int piece = q / PT_W, k = q % PT_W;
+        const int kr = k < TH ? k : TH - 1;
+        double v;
+        if (piece < 2) v = *S(piece, k);                             // top two rows
+        else if (piece < 4) v = *S(TH - 4 + piece, k);               // bottom two rows: TH - 2, TH - 1
+        else if (piece < 6) v = *S(kr, piece - 4);                   // left two columns
+        else v = *S(kr, TWv - 8 + piece);                            // right two columns: TWv - 2, TWv - 1
+        __builtin_amdgcn_raw_buffer_store_b128(tagged(v, tag_lo, tag_hi), rh, (unsigned)q * 16u, 0u, 16 /* sc1 */);
       }
-      stamp(st, kStampStep, 6);                               // border in memory
-      if (tid == 0) st_agent(&rs->hflag[(size_t)bid * 16], (unsigned)(st + 1));
     }
+    stamp(st, kStampStep, 6);                                 // border on its way
   }
   if (gave_up) return;
   // ---- leave: the tile into the output plane (never the plane the launch read from: a neighbour may still be loading its ring)
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
 }  // namespace
 
 size_t cvh_pm_resident_lds_bytes() { return PmResSmem::bytes; }
-int cvh_pm_resident_halo_doubles() { return PT_HALO; }
+int cvh_pm_resident_halo_doubles() { return 2 * PT_HALO; }   // 16-byte entries {value, tag}
 
 namespace {
 typedef void (*PmResKernel)(const CvhPmArgs);
