@@ -244,9 +244,6 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     };
     // samples of row k of the group, channel ch: byte of a | byte of b << 8
     auto samples = [&](int ch, int k) -> int { return (int)*reinterpret_cast<const unsigned short *>(simg + (ch * R + k) * IMGP2 + ibyte); };
-#ifdef CVH_C3_SAMPLES_AHEAD
-    int snext[C];   // (A/B build) three channels: the samples of the NEXT row, read one row ahead -- the table lookups then wait for ONE LDS round trip
-#endif
 
     // ---- prologue
     const double2_t um2 = U(s0 - 2);
@@ -355,17 +352,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       int sa[C], sb[C];                              // samples of pixel a / b per channel
       if (C == 1) { sa[0] = im[k] & 0xff; sb[0] = (im[k] >> 8) & 0xff; }
       else {
-#ifdef CVH_C3_SAMPLES_AHEAD
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          const int s = (k == 0) ? samples(ch, 0) : snext[ch];
-          sa[ch] = s & 0xff; sb[ch] = s >> 8;
-          if (k + 1 < R) snext[ch] = samples(ch, k + 1);
-        }
-#else
+        // (reading the samples one row ahead, so that the table lookups wait for one LDS round trip instead of two: measured, no gain --
+        // DESIGN.md 4.1, the 3-channel paragraph)
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) { const int s = samples(ch, k); sa[ch] = s & 0xff; sb[ch] = s >> 8; }
-#endif
       }
       const int ba = sa[0], bb = sb[0];
 #ifdef CVH_ABLATE_COMPUTE
