@@ -60,10 +60,7 @@ struct PmResSmem {
 static_assert(PmResSmem::bytes <= 160 * 1024, "the tile with its halo ring must fit one CU's LDS");
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // 16-byte agent-scope (sc1) accesses to the border buffer: one entry {value, tag}, one transaction
 __device__ __forceinline__ u32x4s_t ld_line16(const void *base, unsigned byte_off)
@@ -76,13 +73,6 @@ __device__ __forceinline__ u32x4s_t tagged(double v, unsigned tag_lo, unsigned t
   return u32x4s_t{(unsigned)b, (unsigned)(b >> 32), tag_lo, tag_hi};
 }
 
-__device__ __forceinline__ double dpp_from_right(double v)
-{
-  const long long vb = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_mov_dpp((int)vb, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp((int)(vb >> 32), 0x130, 0xf, 0xf, true);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 // lane l gets lane l - 1's v (wave_shr:1) / lane l + 1's (wave_shl:1); the lane without a source -- 0 / 63 -- keeps `old`
 __device__ __forceinline__ double dpp_from_left_or(double old, double v)
 {
@@ -98,13 +88,6 @@ __device__ __forceinline__ double dpp_from_right_or(double old, double v)
   const int hi = __builtin_amdgcn_update_dpp((int)(ob >> 32), (int)(vb >> 32), 0x130, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double read_lane_f64(double v, int l)
-{
-  const long long vb = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)vb, l), hi = __builtin_amdgcn_readlane((int)(vb >> 32), l);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 template <bool FAST, int NR>
 __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmArgs a)
 {
