@@ -1,6 +1,6 @@
 """Perona-Malik data flows against each other, one context per size, the flows alternated: HIP-event us per time step (load / store of
 the uint8 plane included, as bench.py's C4 phase counts them).
-usage: pm_flows.py [SIZES=128,256,512,1024,1536,2048 STEPS=400 REPS=3 FLOWS=3,4]"""
+usage: pm_flows.py [SIZES=128,256,512,1024,1536,2048 STEPS=400 REPS=3 FLOWS=3,4 OPTS=key=value,...]"""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np
@@ -13,6 +13,8 @@ for n in sizes:
     img = synth.disk(n, 200, 50, noise=40, seed=1)
     with capi.Context(n, n, 1) as ctx:
         ctx.set_option("math_mode", math)
+        for kv in os.environ.get("OPTS", "").split(","):      # e.g. OPTS=pm_res_waves=12
+            if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         res = {f: [] for f in flows}
         for r in range(reps + 1):
             for f in flows:
