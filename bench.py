@@ -330,7 +330,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 # the resident kernel runs a chunk of iterations per launch: its counters are recorded per ITERATION (launch total / iterations)
-                traffic = tj.get(f"csv_resident_{n}x{n}x{C}_per_iteration") if (launch or {}).get("kernel") == "csv_resident_kernel" else tj.get(f"csv_step_{n}x{n}x{C}")
+                traffic = tj.get(f"csv_resident_{n}x{n}x{C}_per_iteration") if (launch or {}).get("kernel", "").startswith("csv_resident_kernel") else tj.get(f"csv_step_{n}x{n}x{C}")
                 traffic_source = tj.get("_source") if traffic is not None else None
                 if pm_info is not None and pm_launch is not None:
                     if pm_launch["kernel"].startswith("pm_resident_kernel"):      # one launch for all steps: counters recorded per STEP

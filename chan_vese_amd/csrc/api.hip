@@ -62,6 +62,7 @@ struct cvh_context {
   double *d_res_halo = nullptr;
   double *d_pm_halo = nullptr;   // pm_resident_kernel's border entries {value, tag}: its own buffer (tags must never meet foreign data)
   int *h_resident = nullptr;     // pinned: {arrive, error} of the last launch
+  int res_straight = 1;          // diagnostic option "res_straight": 0 = the generic march of csv_resident_kernel whatever the tile height
   int pm_resident_cap = -1;      // workgroups of pm_resident_kernel the device holds at once (-1: not asked yet)
   unsigned pm_res_serial = 0;    // launches of pm_resident_kernel so far (tag of the border entries; 0 = the cleared buffer)
   int resident_opt = -1;         // option "resident": -1 auto (on where it applies, unless a per-launch knob was set), 0 off, 1 on where it applies
@@ -319,6 +320,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value < -1 || value > 4)
       return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave), 2 (wave, 2 pixels per lane), 3 (wave, 2 time steps per launch) or 4 (resident plane)");
     c->pm_kernel = (int)value;
+  } else if (!strcmp(key, "res_straight")) {
+    c->res_straight = value ? 1 : 0;
   } else if (!strcmp(key, "pm_strip_rows")) {
     if (value < 0) return fail(c, CVH_ERR_ARG, "pm_strip_rows must be >= 0");
     c->pm_strip_rows = (int)value;
@@ -1045,6 +1048,10 @@ static int launch_resident(cvh_context *c, const ResidentGeom &rg, int nsteps, C
     fill_args(c, &a, (c->cur_base + c->enqueued) & 1, c->enqueued);
     if (!a.chain) return fail(c, CVH_ERR_STATE, "resident mode needs chain-mode sums");
     a.tiles_x = rg.tc; a.tiles_y = rg.tr; a.nparts = ntiles;
+    {   // every tile 16, 32, 64 or 128 rows: the straight-line flavour of the march
+      const int th = c->h % rg.tr == 0 ? c->h / rg.tr : 0;
+      a.res_band_rows = (c->res_straight && (th == 16 || th == 32 || th == 64 || th == 128)) ? th / 8 : 0;
+    }
     a.resident = c->d_resident;
     a.res_halo = c->d_res_halo;
     a.res_steps = n;

@@ -135,6 +135,9 @@ __device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int ge
   return res;
 }
 
+// NRT: rows per wave when every tile has exactly 8 * NRT rows (2, 4, 8, 16: the march is straight-line code, row offsets are immediates, the
+// band's last row is known at compile time); 0: any tile height (bands of TH / 8 rows, a loop over groups of four rows)
+template <int NRT>
 __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhStepArgs a)
 {
   using L = ResSmem;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   const double eps = a.eps, eps2 = eps * eps;
   const FarCoef fc = {a.far_k[0], a.far_k[1], a.far_k[2], a.far_k[3], a.far_k[4], a.far_thr};
   // this wave's band of tile rows
-  const int rb0 = (TH * wave) / RT_WAVES, rb1 = (TH * (wave + 1)) / RT_WAVES;
+  const int rb0 = NRT ? NRT * wave : (TH * wave) / RT_WAVES, rb1 = NRT ? rb0 + NRT : (TH * (wave + 1)) / RT_WAVES;
   const int ca = 2 * lane;                                  // tile column of pixel a
   const bool lane_valid = ca < TWv;
   const double fxa = (c0 + ca <= 0) ? 0.0 : 1.0;            // kappa_x(i, 0) = 0 (src/main.cpp:371)
@@ -289,20 +292,30 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       int smp_keep[4];
       unsigned long long near_mask[4];
       // (no branch inside a row: a group of four rows is one basic block and hipcc overlaps the rows' dependent chains)
-      auto row = [&](int i, int k) {
-        const bool lastrow = i + 1 >= rb1;                      // wave-uniform
-        const double2_t up_l = *reinterpret_cast<const double2_t *>(S(i + 1, ca));
-        const double uw_n = *S(i + 1, ca - 1), ue_n = *S(i + 1, ca + 2);   // (unused behind the band's last row)
+      // (rel = row inside the band: a constant in the straight-line flavours, where every address below is base + immediate)
+      double *const pb = S(rb0, ca);
+      const unsigned char *const simg_b = simg + rb0 * RT_W + ca;
+      const double *const snxl_b = snxl + rb0;
+      auto row = [&](int rel, int k) {
+        const bool lastrow = rel + 1 >= (NRT ? NRT : rb1 - rb0);     // wave-uniform; a constant in the straight-line flavours
+        double2_t up;
+        double uw_n = 0.0, ue_n = 0.0;
         // below the band's last row: the copy taken before the march -- the band below may have rewritten its first row already
-        const double2_t up = double2_t{lastrow ? ubot.x : up_l.x, lastrow ? ubot.y : up_l.y};
-        const int smp = (int)*reinterpret_cast<const unsigned short *>(simg + i * RT_W + ca);
+        if (NRT) {
+          if (lastrow) up = ubot;
+          else { up = *reinterpret_cast<const double2_t *>(pb + (rel + 1) * RT_PITCH); uw_n = pb[(rel + 1) * RT_PITCH - 1]; ue_n = pb[(rel + 1) * RT_PITCH + 2]; }
+        } else {
+          const double2_t up_l = *reinterpret_cast<const double2_t *>(pb + (rel + 1) * RT_PITCH);
+          uw_n = pb[(rel + 1) * RT_PITCH - 1]; ue_n = pb[(rel + 1) * RT_PITCH + 2];   // (unused behind the band's last row)
+          up = double2_t{lastrow ? ubot.x : up_l.x, lastrow ? ubot.y : up_l.y};
+        }
+        const int smp = (int)*reinterpret_cast<const unsigned short *>(simg_b + rel * RT_W);
         const int ba = smp & 0xff, bb = smp >> 8;
-        const double nxl0 = snxl[i];
+        const double nxl0 = snxl_b[rel];
         // x-gradients first: nx(b) is the west gradient of lane + 1's a (DPP), nx(a) the west gradient of b
         const double nxa = norm(u0.y, uw, u0.x);
         const double nxb = norm(ue, u0.x, u0.y);
-        const double nxla_d = dpp_from_left(nxb);
-        const double nxla = lane == 0 ? nxl0 : nxla_d;
+        const double nxla = dpp_from_left_or(nxl0, nxb);          // lane 0 has no lane to its left: it keeps the pre-pass's value
         double uda, udb, Ia, Ib;
         const double va = pixel(u0.x, um.x, up.x, nxa, nxla, fxa, nypa, ba, uda, Ia);
         const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nypb, bb, udb, Ib);
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
         // in place: every reader of the old row i has it in registers.  Lanes beyond a ragged tile's width write cells nobody owns
         // (the halo column among them: it was read a row ahead and is refreshed before the next iteration)
-        *reinterpret_cast<double2_t *>(S(i, ca)) = keep[k];
+        *reinterpret_cast<double2_t *>(pb + rel * RT_PITCH) = keep[k];
         acc[0] += hva; acc[0] += hvb;
         acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
         acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
@@ -328,16 +341,31 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
           acc[2] = __builtin_fma((double)(smp_keep[k] >> 8), db, acc[2]);
         }
       };
-      int i = rb0;
-      for (; i + 4 <= rb1; i += 4) {
+      if (NRT >= 4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) row(i + k, k);
-        if ((near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+        for (int g = 0; g < NRT / 4; ++g) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) correct(k);
+          for (int k = 0; k < 4; ++k) row(4 * g + k, k);
+          if ((near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) correct(k);
+          }
         }
+      } else if (NRT == 2) {
+        row(0, 0); correct(0);
+        row(1, 0); correct(0);
+      } else {
+        int rel = 0;
+        for (; rel + 4 <= rb1 - rb0; rel += 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) row(rel + k, k);
+          if ((near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) correct(k);
+          }
+        }
+        for (; rel < rb1 - rb0; ++rel) { row(rel, 0); correct(0); }
       }
-      for (; i < rb1; ++i) { row(i, 0); correct(0); }
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] = lane_valid ? acc[s] : 0.0;   // lanes beyond the image contribute nothing
     }
@@ -531,28 +559,49 @@ int cvh_resident_tile_w() { return RT_W; }
 int cvh_resident_tile_hmax() { return RT_HMAX; }
 int cvh_resident_halo_doubles() { return RT_HALO; }
 
-// Workgroups of the resident kernel one CU holds (0: not launchable, e.g. the LDS request was refused).
+namespace {
+typedef void (*ResKernel)(const CvhStepArgs);
+ResKernel res_kernel(int band_rows)
+{
+  switch (band_rows) {
+    case 0: return csv_resident_kernel<0>;
+    case 2: return csv_resident_kernel<2>;
+    case 4: return csv_resident_kernel<4>;
+    case 8: return csv_resident_kernel<8>;
+    case 16: return csv_resident_kernel<16>;
+  }
+  return nullptr;
+}
+}  // namespace
+
+// Workgroups of the resident kernel one CU holds (0: not launchable, e.g. the LDS request was refused): the least over the flavours.
 int cvh_resident_blocks_per_cu()
 {
   static int cached = -1;
   if (cached >= 0) return cached;
-  int n = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(csv_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ResSmem::bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return cached = 0;
+  int least = 1 << 30;
+  for (int nr = 0; nr <= 16; nr = nr ? 2 * nr : 2) {
+    const void *k = reinterpret_cast<const void *>(res_kernel(nr));
+    int n = 0;
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ResSmem::bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, RT_THREADS, ResSmem::bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return cached = 0;
+    }
+    if (n < least) least = n;
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, csv_resident_kernel, RT_THREADS, ResSmem::bytes) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-  return cached = n;
+  return cached = least;
 }
 
 hipError_t cvh_launch_resident(const CvhStepArgs &a, hipStream_t s)
 {
+  const ResKernel kern = res_kernel(a.res_band_rows);
+  if (!kern) return hipErrorInvalidValue;
   if (a.note) {
-    cvh_fill_note(a.note, (unsigned)(a.tiles_x * a.tiles_y), RT_THREADS, ResSmem::bytes, "csv_resident_kernel");
+    cvh_fill_note(a.note, (unsigned)(a.tiles_x * a.tiles_y), RT_THREADS, ResSmem::bytes, "csv_resident_kernel<%d>", a.res_band_rows);
     return hipSuccess;
   }
   CvhStepArgs copy = a;
   void *params[] = {&copy};
-  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(csv_resident_kernel), dim3(a.tiles_x * a.tiles_y), dim3(RT_THREADS), params,
-                                    (unsigned)ResSmem::bytes, s);
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kern), dim3(a.tiles_x * a.tiles_y), dim3(RT_THREADS), params, (unsigned)ResSmem::bytes, s);
 }

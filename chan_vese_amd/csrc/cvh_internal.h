@@ -124,6 +124,7 @@ struct CvhStepArgs {
   double *res_halo;              // [2][tiles][6 * 128] border rows / columns of every tile, by iteration parity
   int res_steps, res_poll_cap;   // iterations in this launch; polls before a wait gives up
   int res_t0;                    // index of the launch's first iteration inside the run (= iterations enqueued before it)
+  int res_band_rows;             // rows per wave when every tile has 8 x that many rows (2, 4, 8, 16: straight-line march), else 0
 };
 
 // The ONE way a step / Perona-Malik kernel is launched: KERNEL may be a parenthesised template-id; the trailing

@@ -73,14 +73,7 @@ __device__ __forceinline__ u32x4s_t tagged(double v, unsigned tag_lo, unsigned t
   return u32x4s_t{(unsigned)b, (unsigned)(b >> 32), tag_lo, tag_hi};
 }
 
-// lane l gets lane l - 1's v (wave_shr:1) / lane l + 1's (wave_shl:1); the lane without a source -- 0 / 63 -- keeps `old`
-__device__ __forceinline__ double dpp_from_left_or(double old, double v)
-{
-  const long long vb = __double_as_longlong(v), ob = __double_as_longlong(old);
-  const int lo = __builtin_amdgcn_update_dpp((int)ob, (int)vb, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(ob >> 32), (int)(vb >> 32), 0x138, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+// lane l gets lane l + 1's v (wave_shl:1); lane 63 has no source lane and keeps `old` (wave_math.h has the other direction)
 __device__ __forceinline__ double dpp_from_right_or(double old, double v)
 {
   const long long vb = __double_as_longlong(v), ob = __double_as_longlong(old);

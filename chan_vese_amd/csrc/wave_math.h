@@ -105,4 +105,13 @@ __device__ __forceinline__ double dpp_from_left(double v)
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// lane l gets lane l - 1's v (wave_shr:1); lane 0 has no source lane and keeps `old` (bound_ctrl:0): no select for the wave's left edge
+__device__ __forceinline__ double dpp_from_left_or(double old, double v)
+{
+  const long long vb = __double_as_longlong(v), ob = __double_as_longlong(old);
+  const int lo = __builtin_amdgcn_update_dpp((int)ob, (int)vb, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(ob >> 32), (int)(vb >> 32), 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 }  // namespace cvh_dev

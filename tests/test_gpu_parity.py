@@ -122,7 +122,7 @@ def test_launch_info_names_what_runs(capi):
     with capi.Context(1024, 1024, 1) as ctx:      # >= 0.6 Mpixel: the 2-pixel kernel is the default
         ctx.set_image([synth.disk(1024)])
         ctx.init_checkerboard()
-        assert ctx.launch_info()["kernel"] == "csv_resident_kernel"        # the default for a plane that fits the chip's LDS
+        assert ctx.launch_info()["kernel"] == "csv_resident_kernel<4>"       # the default for a plane that fits the chip's LDS: 32 x 8 tiles of 32 rows, 4 per wave
         ctx.set_option("resident", 0)
         i = ctx.launch_info()
         assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1, false>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"

@@ -27,7 +27,7 @@ def resident_ctx(capi, h, w, pk):
     ctx = capi.Context(h, w, 1, capi.make_params(**pk))
     ctx.set_option("resident", 1)
     info = ctx.launch_info()
-    assert info["kernel"] == "csv_resident_kernel", info     # the shape qualifies: otherwise the test would silently test another kernel
+    assert info["kernel"].startswith("csv_resident_kernel<"), info     # the shape qualifies: otherwise the test would silently test another kernel
     return ctx, info
 
 
@@ -134,3 +134,22 @@ def test_resident_2048_against_the_exact_sum_oracle(capi, oracle):
     assert rel_err(u_g, u_e) <= 1e-9, rel_err(u_g, u_e)
     assert np.allclose(tr_g, np.array(tr_e), rtol=1e-9, atol=0)
     assert rel_err(u_g, u_l) <= 1e-9
+
+
+@pytest.mark.parametrize("shape,flavour", [((16, 128), 2), ((64, 256), 2), ((128, 128), 2), ((512, 512), 2), ((1024, 1024), 4), ((2048, 1024), 8),
+                                           ((2048, 2048), 16)])
+def test_resident_straight_line_flavours_are_the_generic_march_bit_for_bit(capi, shape, flavour):
+    """Tiles of exactly 16 / 32 / 64 / 128 rows run csv_resident_kernel<2 | 4 | 8 | 16>: the same march as straight-line code (row offsets
+    immediate, the band's last row known at compile time, no register rotation).  Same operations in the same order: level set and trace
+    are those of the generic flavour (option "res_straight" = 0) bit for bit."""
+    h, w = shape
+    img = synth.disk(max(h, w), 200, 50, noise=30, seed=5, h=h, w=w)
+    outs = []
+    for straight in (1, 0):
+        with capi.Context(h, w, 1, capi.make_params(tol=0, nu=0.01)) as ctx:
+            ctx.set_option("resident", 1); ctx.set_option("res_straight", straight); ctx.set_option("trace", 25)
+            assert ctx.launch_info()["kernel"] == "csv_resident_kernel<%d>" % (flavour if straight else 0)
+            ctx.set_image([img]); ctx.init_checkerboard()
+            assert ctx.run(25)[0] == 25
+            outs.append((ctx.get_levelset(), ctx.get_trace(25)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
