@@ -38,6 +38,12 @@ namespace {
 constexpr int RT_W = 128;                 // tile width: 64 lanes x 2 pixels
 constexpr int RT_HMAX = 128;              // most rows a tile may have (LDS)
 constexpr int RT_PITCH = 132;             // doubles per LDS row: tile columns -2 .. 129
+#ifndef CVH_RES_MSLEEP
+#define CVH_RES_MSLEEP 1                  // s_sleep between the master's polls of the arrival lines (A/B builds)
+#endif
+#ifndef CVH_RES_GSLEEP
+#define CVH_RES_GSLEEP 3                  // s_sleep between a workgroup's polls of its release line (A/B builds)
+#endif
 #ifndef CVH_RT_WAVES
 #define CVH_RT_WAVES 8                    // waves per workgroup (A/B builds: 16 = 4 per SIMD at <= 128 VGPRs)
 #endif
@@ -123,7 +129,7 @@ __device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int ge
       const u32x4r_t ga = ld_line16(rs->go, (unsigned)bid * 64u), gb = ld_line16(rs->go, (unsigned)bid * 64u + 16u);
       if (ga.x == gb.x && ga.x >= (unsigned)gen && ga.x != 0xffffffffu) { res = (int)(ga.y & 1u); m1 = line16_f64(ga); m2 = line16_f64(gb); break; }
       if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(3);
+      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(CVH_RES_GSLEEP);
     }
     if (res < 0) st_agent(const_cast<int *>(&rs->error), 1);
     s_bc[0] = (double)res; s_bc[1] = m1; s_bc[2] = m2;
@@ -412,6 +418,8 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       const bool have = b < ntiles;
       bool done = false;
       u32x4r_t fa = {0u, 0u, 0u, 0u}, fb = {0u, 0u, 0u, 0u};
+      // (one poll in flight: two in flight, half a round trip apart, sample a line twice as often and are SLOWER -- 2048^2 14.60 -> 15.04 us,
+      // 1024^2 7.89 -> 8.19: reads of a line that is being written get in the way of the write)
       for (int round = 0; round < a.res_poll_cap; ++round) {
         if (have) {
           fa = ld_line16(rs->flag, (unsigned)b * 64u + (lane < 32 ? 0u : 32u));
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         const bool ok = !have || (fa.x >= gen && fa.x != 0xffffffffu && (lane >= 32 || (fb.x >= gen && fb.x != 0xffffffffu)));
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { done = true; break; }
         if ((round & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(CVH_RES_MSLEEP);
       }
       if (done) {
         const double ws = wave_sum((have && lane < 32) ? line16_f64(fa) : 0.0);                       // fixed order: lane = tile
