@@ -18,7 +18,7 @@
 //   1 = 2-pixel kernel (default), 2 = 1-pixel kernel too), "wave_cskew" per-mille strip-length skew between dispatch rounds (500),
 //   "wave_pol" = 2 (diagnostic value of the public option: plain stores with non-temporal loads),
 //   "chain" fixed-point chained sums + deferred bookkeeping in the wave kernels (1), "far_terms" terms of the far-field series (5; 4), "wave_lds_cap", "wave_rev", "debug_times" (per-wave stamps
-//   read with cvh_debug_read, tools/wave_timeline.py).
+//   read with cvh_debug_read, tools/wave_timeline.py), "res_straight" (1; 0 = csv_resident_kernel's generic march whatever the tile height).
 
 // Device-resident scalar state of one context.  Written only by the finalising workgroup
 // of a kernel and read by the next kernel on the same stream (kernel boundary = visibility).

@@ -13,7 +13,7 @@ for n in sizes:
     img = synth.disk(n, 200, 50, noise=40, seed=1)
     with capi.Context(n, n, 1) as ctx:
         ctx.set_option("math_mode", math)
-        for kv in os.environ.get("OPTS", "").split(","):      # e.g. OPTS=pm_res_waves=12
+        for kv in os.environ.get("OPTS", "").split(","):      # e.g. OPTS=wave_pol=0
             if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         res = {f: [] for f in flows}
         for r in range(reps + 1):
