@@ -382,7 +382,8 @@ def test_kernel_flavours_agree_at_4096(capi):
     for opts, ref in ((dict(kernel=3), ref_fast), (dict(kernel=3, wave_pol=0), ref_fast), (dict(kernel=3, wave_pol=2), ref_fast),
                       (dict(kernel=3, wave_occupancy=4), ref_fast), (dict(kernel=3, chain=0), ref_fast),
                       (dict(kernel=3, strip_rows=100, wave_cls=0), ref_fast), (dict(kernel=3, math_mode=1), ref_strict),
-                      (dict(kernel=1), ref_fast), (dict(kernel=0), ref_fast), (dict(kernel=2, chain=0), ref_fast)):
+                      (dict(kernel=1), ref_fast), (dict(kernel=0), ref_fast), (dict(kernel=2, chain=0), ref_fast),
+                      (dict(kernel=3, wave_sync=0), ref_fast), (dict(kernel=2, wave_sync=0), ref_fast)):
         d = np.abs(run(opts) - ref).max()
         assert d <= 1e-9 * scale, (opts, d)
 
@@ -429,7 +430,9 @@ def test_three_channel_flavours_agree_at_4096(capi):
 
     ref = run(dict(kernel=2))
     scale = np.abs(ref).max()
-    for opts in (dict(kernel=3), dict(kernel=3, lut=0), dict(kernel=3, wave_pol=1), dict(kernel=3, chain=0)):
+    # ("wave_sync": the workgroup barrier per group of rows -- a scheduling matter, off by default for three channels, on for one)
+    for opts in (dict(kernel=3), dict(kernel=3, lut=0), dict(kernel=3, wave_pol=1), dict(kernel=3, chain=0), dict(kernel=3, wave_sync=1),
+                 dict(kernel=2, wave_sync=1)):
         d = np.abs(run(opts) - ref).max()
         assert d <= 1e-9 * scale, (opts, d)
 
