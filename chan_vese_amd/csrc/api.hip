@@ -1386,6 +1386,9 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
     return fail(c, CVH_ERR_ARG, "The segmentation duration must exceed the value of Laplacian coefficient, %f.", L);
   if (K == 0) return fail(c, CVH_ERR_ARG, "cvh_perona_malik: edge coefficient K must be non-zero");
   HIPCHK(c, hipSetDevice(c->device));
+  // CSV work that was enqueued and never synchronised is closed first, as cvh_set_image does: the resident Perona-Malik flow clears the
+  // shared CvhResident block (the error word of an unsynchronised csv_resident_kernel launch with it) and reuses ev0 / ev1.
+  if (c->timing_open || c->chain_pending || c->resident_used) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
   const int trips = cvh_pm_trip_count(L, T);
   for (int k = 0; k < 2; ++k)
     if (!c->d_pm[k]) HIPCHK(c, hipMalloc((void **)&c->d_pm[k], c->n * sizeof(double)));
