@@ -41,6 +41,7 @@ struct cvh_context {
   int pm_kernel = -1;   // -1 auto, 0 tile kernel, 1 wave kernel, 2 wave kernel with 2 pixels per lane
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = -1 /* auto: 1 channel 1, 3 channels 0 */, wave_imgv = 1, wave_depth = 4;
+  int near_switch = 1;  // option "near_switch": per-wave, per-group choice of the form of H_eps (csv_wave2_kernel.hip); 0 = far form + correction always
   double *d_dummy = nullptr;
   int wave_rev = 0, wave_xcd = 1;
   int use_graph = 1;
@@ -370,6 +371,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     c->wave_imgv = value != 0;
   } else if (!strcmp(key, "wave_sync")) {
     c->wave_sync = value < 0 ? -1 : (value != 0);
+  } else if (!strcmp(key, "near_switch")) {
+    c->near_switch = value != 0;
   } else if (!strcmp(key, "wave_prio")) {
     if (value < 0 || value > 4) return fail(c, CVH_ERR_ARG, "wave_prio must be 0..4");
     c->wave_prio = (int)value;
@@ -770,6 +773,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   // workgroup barrier per group of four rows: keeps a workgroup's waves on neighbouring rows (cache locality) -- worth it for one channel;
   // with three channels the barrier costs more than the locality returns (4096^2 x 3, one context: 73.0-74.4 -> 71.9-73.2 us)
   a->wave_sync = c->wave_sync >= 0 ? c->wave_sync : (c->C == 3 ? 0 : 1);
+  a->near_switch = c->near_switch;
   a->wave_depth = c->wave_depth;
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;

@@ -30,6 +30,7 @@
 #include "buffer_ops.h"
 #include "wave_math.h"
 #include "chain_device.h"
+#include <type_traits>
 
 using namespace cvh_dev;
 
@@ -158,6 +159,8 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   double *s_bc = smem + L::off_flag;      // 4 doubles of broadcast scratch
   int *s_flag = (int *)(s_bc + 3);
   int *s_mflag = s_flag + 12;             // master workgroup: generation each wave's share of the arrivals is complete for
+  constexpr unsigned kLutAddr = (unsigned)(L::off_lut * sizeof(double));   // LDS byte address of the region-term table (the dynamic block starts at 0)
+  if (!lds_base_is_zero(smem)) __builtin_trap();                          // (folds away: no static LDS in this kernel)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
                        double &Ik_out) -> double {
         const double ny = norm(s_, n_, c);
         const double kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
-        const double2_t e = reinterpret_cast<const double2_t *>(slut)[byte];
+        const double2_t e = lds_read_d2(kLutAddr + (unsigned)byte);      // `byte`: the entry's byte offset (sample x 16)
         double ud = __builtin_fma(kappa, a.alpha, e.x);                  // :985
         const double qd = __builtin_fma(c, c, eps2) * a.dk1;             // 1 / delta_eps(u)
         const double q0 = __builtin_amdgcn_rcp(qd);
@@ -296,13 +299,19 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       // the contour are corrected per group of four rows (csv_wave2_kernel.hip, DEFER)
       double2_t keep[4];
       int smp_keep[4];
-      unsigned long long near_mask[4];
+      unsigned long long near_any = 0ull;   // lanes below the far-field threshold in the current group of rows (one mask, not four)
       // (no branch inside a row: a group of four rows is one basic block and hipcc overlaps the rows' dependent chains)
       // (rel = row inside the band: a constant in the straight-line flavours, where every address below is base + immediate)
       double *const pb = S(rb0, ca);
       const unsigned char *const simg_b = simg + rb0 * RT_W + ca;
       const double *const snxl_b = snxl + rb0;
-      auto row = [&](int rel, int k) {
+      // Which form of H_eps a BAND takes this iteration is decided per wave from its first row (csv_wave2_kernel.hip, near_strip): where
+      // most of that row is below the far-field threshold the wave runs the copy of the march that takes the table form of every
+      // pixel behind the rows of a group (valid for any u, nothing to correct) -- one form per pixel instead of three.
+      const bool near_band = a.near_switch &&
+          __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane_valid && (fabs(u0.x) < fc.thr || fabs(u0.y) < fc.thr))) >= 32;
+      auto row = [&](int rel, int k, auto near_tag) {
+        constexpr bool NEARFORM = decltype(near_tag)::value;
         const bool lastrow = rel + 1 >= (NRT ? NRT : rb1 - rb0);     // wave-uniform; a constant in the straight-line flavours
         double2_t up;
         double uw_n = 0.0, ue_n = 0.0;
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
           up = double2_t{lastrow ? ubot.x : up_l.x, lastrow ? ubot.y : up_l.y};
         }
         const int smp = (int)*reinterpret_cast<const unsigned short *>(simg_b + rel * RT_W);
-        const int ba = smp & 0xff, bb = smp >> 8;
+        const int ba = (int)byte_x16<0>((unsigned)smp), bb = (int)byte_x16<1>((unsigned)smp);   // sample x 16 in one SDWA instruction each (wave_math.h)
         const double nxl0 = snxl_b[rel];
         // x-gradients first: nx(b) is the west gradient of lane + 1's a (DPP), nx(a) the west gradient of b
         const double nxa = norm(u0.y, uw, u0.x);
@@ -327,51 +336,65 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         const double vb = pixel(u0.y, um.y, up.y, nxb, nxa, 1.0, nypb, bb, udb, Ib);
         keep[k] = double2_t{va, vb};
         smp_keep[k] = smp;
-        const double hva = heaviside_centred_far(va, fc), hvb = heaviside_centred_far(vb, fc);
-        near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
         // in place: every reader of the old row i has it in registers.  Lanes beyond a ragged tile's width write cells nobody owns
         // (the halo column among them: it was read a row ahead and is refreshed before the next iteration)
         *reinterpret_cast<double2_t *>(pb + rel * RT_PITCH) = keep[k];
-        acc[0] += hva; acc[0] += hvb;
-        acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
+        if (!NEARFORM) {
+          const double hva = heaviside_centred_far(va, fc), hvb = heaviside_centred_far(vb, fc);
+          near_any |= __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
+          acc[0] += hva; acc[0] += hvb;
+          acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
+        }
         acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
         um = u0; u0 = up; uw = uw_n; ue = ue_n;
       };
-      auto correct = [&](int k) {
-        if (near_mask[k] != 0ull) {
+      auto correct = [&](int k, auto near_tag) {
+        constexpr bool NEARFORM = decltype(near_tag)::value;
+        if (NEARFORM || __builtin_amdgcn_ballot_w64(fabs(keep[k].x) < fc.thr || fabs(keep[k].y) < fc.thr) != 0ull) {
           const double xa = keep[k].x, xb = keep[k].y;
-          const double da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
-          const double db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
+          double da, db;
+          if (NEARFORM) {   // the rows added nothing for H
+            da = heaviside_centred_near(xa, a.inv_eps, satan); db = heaviside_centred_near(xb, a.inv_eps, satan);
+          } else {
+            da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
+            db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
+          }
           acc[0] += da; acc[0] += db;
           acc[2] = __builtin_fma((double)(smp_keep[k] & 0xff), da, acc[2]);
           acc[2] = __builtin_fma((double)(smp_keep[k] >> 8), db, acc[2]);
         }
       };
-      if (NRT >= 4) {
+      auto march = [&](auto near_tag) {
+        constexpr bool NEARFORM = decltype(near_tag)::value;
+        if (NRT >= 4) {
 #pragma unroll
-        for (int g = 0; g < NRT / 4; ++g) {
+          for (int g = 0; g < NRT / 4; ++g) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) row(4 * g + k, k);
-          if ((near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+            for (int k = 0; k < 4; ++k) row(4 * g + k, k, near_tag);
+            if (NEARFORM || near_any != 0ull) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) correct(k);
+              for (int k = 0; k < 4; ++k) correct(k, near_tag);
+            }
+            near_any = 0ull;
           }
-        }
-      } else if (NRT == 2) {
-        row(0, 0); correct(0);
-        row(1, 0); correct(0);
-      } else {
-        int rel = 0;
-        for (; rel + 4 <= rb1 - rb0; rel += 4) {
+        } else if (NRT == 2) {
+          row(0, 0, near_tag); correct(0, near_tag);
+          row(1, 0, near_tag); correct(0, near_tag);
+        } else {
+          int rel = 0;
+          for (; rel + 4 <= rb1 - rb0; rel += 4) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) row(rel + k, k);
-          if ((near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+            for (int k = 0; k < 4; ++k) row(rel + k, k, near_tag);
+            if (NEARFORM || near_any != 0ull) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) correct(k);
+              for (int k = 0; k < 4; ++k) correct(k, near_tag);
+            }
+            near_any = 0ull;
           }
+          for (; rel < rb1 - rb0; ++rel) { row(rel, 0, near_tag); correct(0, near_tag); }
         }
-        for (; rel < rb1 - rb0; ++rel) { row(rel, 0); correct(0); }
-      }
+      };
+      if (near_band) march(std::true_type{}); else march(std::false_type{});
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] = lane_valid ? acc[s] : 0.0;   // lanes beyond the image contribute nothing
     }

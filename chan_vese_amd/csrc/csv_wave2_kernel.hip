@@ -41,6 +41,8 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   double *satan = smem + L::off_atan;
   double *slut = smem + L::off_lut;
   int *s_last = (int *)(smem + L::off_flag);
+  constexpr unsigned kLutAddr = (unsigned)(L::off_lut * sizeof(double));   // LDS byte address of the region-term table (the dynamic block starts at 0)
+  if (!lds_base_is_zero(smem)) __builtin_trap();                          // (folds away: no static LDS in this kernel)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       double kappa, ud, Ik;
       if (FAST) {
         kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
-        const double2_t e = reinterpret_cast<const double2_t *>(slut)[byte];
+        const double2_t e = lds_read_d2(kLutAddr + (unsigned)byte);   // FAST: `byte` is the entry's byte offset (sample x 16)
         Ik = e.y;
         ud = __builtin_fma(kappa, a.alpha, e.x);                       // :985
         const double qd = __builtin_fma(c, c, eps2) * a.dk1;           // 1/delta_eps(u)
@@ -319,16 +321,15 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
         reg = qc;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
-          Ik[ch] = (double)byte[ch];
+          Ik[ch] = (double)(byte[ch] >> 4);
           reg = __builtin_fma(__builtin_fma(qa[ch], Ik[ch], qb[ch]), Ik[ch], reg);
         }
       } else {
-        const double2_t *lut2 = reinterpret_cast<const double2_t *>(slut);
-        const double2_t e0 = lut2[byte[0]];
+        const double2_t e0 = lds_read_d2(kLutAddr + (unsigned)byte[0]);   // `byte[ch]` is the entry's byte offset inside channel ch's table (sample x 16)
         reg = e0.x; Ik[0] = e0.y;
 #pragma unroll
         for (int ch = 1; ch < C; ++ch) {
-          const double2_t e = lut2[ch * 256 + byte[ch]];
+          const double2_t e = lds_read_d2(kLutAddr + (unsigned)(ch * 4096) + (unsigned)byte[ch]);
           reg += e.x; Ik[ch] = e.y;
         }
       }
@@ -345,23 +346,27 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     // DEFER (3 waves/SIMD: register room): rows without a branch, see csv_wave_kernel.hip
     constexpr bool DEFER = FAST && MINW <= 3;
     double2_t keep[R];
-    unsigned long long near_mask[R];
-    auto row = [&](int i, int k, bool live) {
+    unsigned long long near_any = 0ull;   // lanes that met a pixel below the far-field threshold in this group's rows (ONE mask: four would spill SGPRs into VGPRs)
+    int smp3[C][R];   // NEARFORM, three channels: the group's samples, taken aside before the park refills the image tile
+    auto row = [&](int i, int k, bool live, auto near_tag) {
+      constexpr bool NEARFORM = decltype(near_tag)::value;   // this group evaluates H_eps in its table form on every lane (below)
       const double2_t up = x_own[k * (XP2 / 2)];
       const double uw_n = x_w[k * XP2], ue_n = x_e[k * XP2];
       int sa[C], sb[C];                              // samples of pixel a / b per channel
-      if (C == 1) { sa[0] = im[k] & 0xff; sb[0] = (im[k] >> 8) & 0xff; }
-      else {
+      // FAST: sample x 16 = the byte offset of its 16-byte table entry, one SDWA instruction per sample (wave_math.h); STRICT: the sample
+      if (C == 1) {
+        if (FAST) { sa[0] = (int)byte_x16<0>((unsigned)im[k]); sb[0] = (int)byte_x16<1>((unsigned)im[k]); }
+        else { sa[0] = im[k] & 0xff; sb[0] = (im[k] >> 8) & 0xff; }
+      } else {
         // (reading the samples one row ahead, so that the table lookups wait for one LDS round trip instead of two: measured, no gain --
         // DESIGN.md 4.1, the 3-channel paragraph)
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) { const int s = samples(ch, k); sa[ch] = s & 0xff; sb[ch] = s >> 8; }
+        for (int ch = 0; ch < C; ++ch) { const unsigned s = (unsigned)samples(ch, k); sa[ch] = (int)byte_x16<0>(s); sb[ch] = (int)byte_x16<1>(s); }
       }
       const int ba = sa[0], bb = sb[0];
 #ifdef CVH_ABLATE_COMPUTE
       {   // keeps every load, LDS exchange and the store; no arithmetic
-        keep[k] = double2_t{u0.x + (up.x + um.x + uw) * 1e-30 + (double)ba * 1e-30, u0.y + (up.y + um.y + ue) * 1e-30 + (double)bb * 1e-30};
-        near_mask[k] = 0ull;
+        keep[k] = double2_t{u0.x + (up.x + um.x + uw) * 1e-30 + (double)(ba >> 4) * 1e-30, u0.y + (up.y + um.y + ue) * 1e-30 + (double)(bb >> 4) * 1e-30};
         buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
         acc[0] += keep[k].x; acc[4] += 1.0;   // a non-zero norm: the stop rule must not fire
         um = u0; u0 = up; uw = uw_n; ue = ue_n;
@@ -391,9 +396,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       // it there anyway, the others pin it below), so nothing writes it for hundreds of instructions, and
       // tools/isa_store_hazard.py checks the emitted ISA of every instantiation (tests/test_isa_hazard.py).
       keep[k] = double2_t{va, vb};
-      if (FAST && DEFER) {   // far-field form on every lane; near lanes are corrected once per group (no branch in a row)
+      if (FAST && DEFER && NEARFORM) {   // H_eps of the whole group is taken behind its rows, in the table form (group())
+        hva = 0.0; hvb = 0.0;
+      } else if (FAST && DEFER) {   // far-field form on every lane; near lanes are corrected once per group (no branch in a row)
         hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
-        near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
+        near_any |= __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
       } else if (FAST) {   // far/near decided per WAVE for both pixels (uniform branch)
         if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {
           hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
@@ -405,7 +412,9 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       }
       buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {
-        if (FAST && C == 1) {
+        if (FAST && DEFER && NEARFORM) {   // the sums of H follow behind the rows
+          acc[2 + 2 * C] = __builtin_fma(uda, uda, acc[2 + 2 * C]); acc[2 + 2 * C] = __builtin_fma(udb, udb, acc[2 + 2 * C]);
+        } else if (FAST && C == 1) {
           acc[0] += hva; acc[0] += hvb;
           acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
           acc[4] = __builtin_fma(uda, uda, acc[4]); acc[4] = __builtin_fma(udb, udb, acc[4]);
@@ -428,8 +437,9 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
 
     int prio = 3;
     if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
-    auto group = [&](int ib, auto interior_tag) {
+    auto group = [&](int ib, auto interior_tag, auto near_tag) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
+      constexpr bool NEARFORM = decltype(near_tag)::value;
       if (a.wave_sync) { __builtin_amdgcn_s_barrier(); ++groups_done; }
       if (a.wave_prio) {
         // At equal priority the SIMD arbiter serves its OLDEST wave first: the 4 waves of a SIMD then run almost
@@ -462,40 +472,81 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        if (INTERIOR || (ib + k) < s1) row(ib + k, k, true);   // wave-uniform: rows past the strip end cost nothing
-        else near_mask[k] = 0ull;
+        if (INTERIOR || (ib + k) < s1) row(ib + k, k, true, near_tag);   // wave-uniform: rows past the strip end cost nothing
       }
-      if (DEFER && (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
+      const bool any_near = near_any != 0ull;
+      near_any = 0ull;
+      // H_eps - 1/2 of row k's pair from keep[k]: TABLE true = the table form of every pixel (the rows of a NEARFORM group added nothing for H),
+      // else the per-group correction of the lanes below the far-field threshold (the rows added the far form on every lane)
+      auto finish_row = [&](int k, int smp0, auto table_tag) {
+        constexpr bool TABLE = decltype(table_tag)::value;
+        const double xa = keep[k].x, xb = keep[k].y;
+        double da, db;
+        if (TABLE) {
+          da = heaviside_centred_near(xa, a.inv_eps, satan); db = heaviside_centred_near(xb, a.inv_eps, satan);
+        } else {
+          da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
+          db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
+        }
+        acc[0] += da; acc[0] += db;
+        if (C == 1) {
+          acc[2] = __builtin_fma((double)(smp0 & 0xff), da, acc[2]);
+          acc[2] = __builtin_fma((double)((smp0 >> 8) & 0xff), db, acc[2]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-          if (near_mask[k] != 0ull && (INTERIOR || (ib + k) < s1)) {
-            const double xa = keep[k].x, xb = keep[k].y;
-            const double da = (fabs(xa) < fc.thr) ? heaviside_centred_near(xa, a.inv_eps, satan) - heaviside_centred_far(xa, fc) : 0.0;
-            const double db = (fabs(xb) < fc.thr) ? heaviside_centred_near(xb, a.inv_eps, satan) - heaviside_centred_far(xb, fc) : 0.0;
-            acc[0] += da; acc[0] += db;
-            if (C == 1) {
-              acc[2] = __builtin_fma((double)(im[k] & 0xff), da, acc[2]);
-              acc[2] = __builtin_fma((double)((im[k] >> 8) & 0xff), db, acc[2]);
-            } else {
-#pragma unroll
-              for (int ch = 0; ch < C; ++ch) {
-                const int s = samples(ch, k);
-                acc[2 + ch] = __builtin_fma((double)(s & 0xff), da, acc[2 + ch]);
-                acc[2 + ch] = __builtin_fma((double)(s >> 8), db, acc[2 + ch]);
-              }
-            }
+          for (int ch = 0; ch < C; ++ch) {
+            const int s = TABLE ? smp3[ch][k] : samples(ch, k);
+            acc[2 + ch] = __builtin_fma((double)(s & 0xff), da, acc[2 + ch]);
+            acc[2 + ch] = __builtin_fma((double)(s >> 8), db, acc[2 + ch]);
           }
         }
-      }
+      };
+      if (DEFER && !NEARFORM && any_near) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) asm volatile("; row %2 of the group: store data still live" :: "v"(keep[k].x), "v"(keep[k].y), "n"(0));
-      park(T, X, IQ);
+        for (int k = 0; k < R; ++k)
+          if ((INTERIOR || (ib + k) < s1) &&        // (which rows: asked again here, on the rare path, instead of keeping four masks)
+              __builtin_amdgcn_ballot_w64(fabs(keep[k].x) < fc.thr || fabs(keep[k].y) < fc.thr) != 0ull) finish_row(k, im[k], std::false_type{});
+      }
+      if (DEFER && NEARFORM) {
+        // the table forms come BEHIND the park: the prefetched rows (22 registers) are in the ring by then, and the forms of eight pixels
+        // have the registers to overlap.  The group's samples are taken aside first (the park refills im[] / the image tile).
+        int smp1[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          smp1[k] = (C == 1) ? im[k] : 0;
+          if (C > 1) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) smp3[ch][k] = samples(ch, k);
+          }
+        }
+        park(T, X, IQ);
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (INTERIOR || (ib + k) < s1) finish_row(k, smp1[k], std::true_type{});
+#pragma unroll
+        for (int k = 0; k < R; ++k) asm volatile("; row %2 of the group: store data still live" :: "v"(keep[k].x), "v"(keep[k].y), "n"(0));
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) asm volatile("; row %2 of the group: store data still live" :: "v"(keep[k].x), "v"(keep[k].y), "n"(0));
+        park(T, X, IQ);
+      }
     };
     const unsigned long long t_first = a.dbg_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // prologue done
     if (a.dbg_times && lane == 0) a.dbg_times[(size_t)(blockIdx.x * 4 + wave) * 4 + 2] = t_first;
     int ib = s0;
-    for (; ib + 2 * R <= ulast; ib += R) group(ib, std::true_type{});
-    for (; ib < s1; ib += R) group(ib, std::false_type{});
+    // Which form of H_eps a STRIP takes is decided per wave from its first row: where most of the row's pixels are below the far-field
+    // threshold (a level set that is near everywhere: dt << 1, the reference README's second example; the first iterations of a
+    // checkerboard start) the wave runs the copy of the march that evaluates the table form on every lane, behind the rows of a group
+    // -- valid for any u, nothing to correct: one form per pixel instead of three (far + near + far again in the correction).
+    const bool near_strip = DEFER && a.near_switch &&
+        __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane_valid && (fabs(u0.x) < fc.thr || fabs(u0.y) < fc.thr))) >= 32;
+    if (__builtin_expect(DEFER && near_strip, 0)) {   // cold for the register allocator: whatever has to spill spills in this copy, not in the far-field march
+      for (; ib + 2 * R <= ulast; ib += R) group(ib, std::true_type{}, std::true_type{});
+      for (; ib < s1; ib += R) group(ib, std::false_type{}, std::true_type{});
+    } else {
+      for (; ib + 2 * R <= ulast; ib += R) group(ib, std::true_type{}, std::false_type{});
+      for (; ib < s1; ib += R) group(ib, std::false_type{}, std::false_type{});
+    }
     const double vmask = lane_valid ? 1.0 : 0.0;   // exact: halo / out-of-image lanes contribute nothing
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = acc[s] * vmask;

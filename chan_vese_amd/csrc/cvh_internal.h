@@ -109,6 +109,7 @@ struct CvhStepArgs {
   int wave_depth;                // wave kernel: rows of u kept in flight per lane (4 or 8)
   int wave_sync;                 // wave kernel: workgroup barrier every 4 rows
   int wave_prio;                 // progress-based s_setprio in the wave kernel
+  int near_switch;               // FAST wave / resident kernels: a wave that met near-field pixels runs its next group of rows in the table form of H_eps
   int wave_lds_cap;              // pad the LDS request so that at most wave_minw workgroups fit a CU
   CvhChainAcc *chain;            // chain mode (2-pixel wave kernel, FAST): fixed-point sum sets, or null
   int chain_phase;               // set this launch reads

@@ -97,6 +97,32 @@ __device__ __forceinline__ double normalised4(double fwd, double bwd, double cen
 #endif
 }
 
+// Byte BYTE (0 or 1) of `word` times 16 -- the byte offset of a 16-byte {term, sample} table entry -- in ONE instruction: an SDWA
+// operand select on the shift (hipcc emits v_and / v_bfe + v_lshl_add: two).  The kernels are bound by the instructions a wave issues.
+template <int BYTE>
+__device__ __forceinline__ unsigned byte_x16(unsigned word)
+{
+  static_assert(BYTE == 0 || BYTE == 1, "the samples of a lane's two pixels are bytes 0 and 1 of the word");
+  unsigned r;
+  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(word));
+  else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(word));
+  return r;
+}
+
+// 16-byte LDS read at an INTEGER byte address.  The kernels' only LDS is the dynamic `extern __shared__` block, which starts at LDS
+// address 0 (lds_base_is_zero() guards that): a table entry's address is then (sample x 16) + a compile-time constant, and the constant
+// rides in the instruction's offset field -- through a generic pointer hipcc adds the block's (relocatable, zero) base with a
+// v_add_u32 per lookup.
+typedef double lds_double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lds_double2_t lds_read_d2(unsigned byte_addr)
+{
+  return *(const __attribute__((address_space(3))) lds_double2_t *)(unsigned long)byte_addr;
+}
+__device__ __forceinline__ bool lds_base_is_zero(const void *dynamic_smem)
+{
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)dynamic_smem == 0u;
+}
+
 __device__ __forceinline__ double dpp_from_left(double v)
 {
   const long long vb = __double_as_longlong(v);

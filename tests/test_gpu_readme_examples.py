@@ -80,13 +80,14 @@ def test_readme_example_through_the_c_abi(capi, oracle, name, mode, math):
             else:
                 assert np.abs(diff).max() <= 1 and (diff != 0).mean() <= 1e-6
         ctx.set_image(pm_c)       # identical input for the CSV part even if a boundary pixel rounded the other way
-        assert abs(ctx.get_stop_condition() - leg["stop"]) <= 1e-12 * leg["stop"]
         ctx.set_option("trace", N)
         ctx.init_checkerboard()
+        assert abs(ctx.get_stop_condition() - leg["stop"]) <= 1e-12 * leg["stop"]     # src/main.cpp:950-959
         done, _ = ctx.run(10)
         assert done == 10
         assert rel_err(ctx.get_levelset(), leg["u10"]) <= 1e-9
-        done, nrm = ctx.run(N - 10)                                  # continues: src/main.cpp:963 up to -N
+        more, nrm = ctx.run(N - 10)                                  # continues (cvh_run counts the iterations of THIS call): src/main.cpp:963 up to -N
+        done = 10 + more
         u_g, tr_g, m_g = ctx.get_levelset(), ctx.get_trace(N), ctx.get_mask()
         assert done == leg["done"]                                   # the stop test (:1000) fires at the same iteration, or never
     assert np.allclose(tr_g[:10], leg["tr"][:10], rtol=1e-9, atol=0)

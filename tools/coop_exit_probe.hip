@@ -1,7 +1,7 @@
 // Probe for the abort recorded in profiles/r03_C4/summary.txt: every rocprofv3 pass of a process that issued COOPERATIVE launches
 // ended in "Segmentation fault" inside exit().  This program has nothing of libchanvese_hip.so in it: an empty kernel, launched
 // either plainly or with hipLaunchCooperativeKernel, with everything it created torn down explicitly before main returns.
-//   ./coop_exit_probe plain | coop | coop_null | coop_leak
+//   ./coop_exit_probe plain | coop | coop_null | coop_leak  [maps]     (maps: print the executable mappings before returning)
 // plain      <<<>>> on a non-blocking stream
 // coop       hipLaunchCooperativeKernel on a non-blocking stream; stream synchronised and destroyed, buffer freed
 // coop_null  the same on the null stream
@@ -39,6 +39,13 @@ int main(int argc, char **argv)
   if (std::strcmp(mode, "coop_leak")) {
     if (s) CK(hipStreamDestroy(s));
     CK(hipFree(d));
+  }
+  if (argc > 2 && !std::strcmp(argv[2], "maps")) {   // executable mappings of this process: which object owns a faulting frame
+    if (FILE *f = std::fopen("/proc/self/maps", "r")) {
+      char line[512];
+      while (std::fgets(line, sizeof(line), f)) if (std::strstr(line, " r-xp ") || std::strstr(line, " r-x")) std::fputs(line, stdout);
+      std::fclose(f);
+    }
   }
   std::printf("probe %s: value %d, returning from main\n", mode, h);
   std::fflush(stdout);

@@ -20,6 +20,7 @@ for n in [int(s) for s in os.environ.get("SIZES", "4096,2048").split(",")]:
             for r in range(reps):
                 ctx.warm(steps); ctx.enqueue_steps(steps); ctx.sync()
                 t.append(ctx.last_run_ms() * 1e3 / steps)
-            u = ctx.get_levelset()
-            print("%5d^2 x%d %-40s %s  median %.2f us   kernel %s   |u|<32: %.4f of the pixels, max|u| %.2f" % (
-                n, C_, label, " ".join("%.2f" % v for v in t), np.median(t), ctx.launch_info()["kernel"], (np.abs(u) < 32).mean(), np.abs(u).max()), flush=True)
+            u = ctx.get_levelset(); m = ctx.get_mask().astype(bool); d = planes[0] > 100
+            iou = max((m & d).sum() / max((m | d).sum(), 1), (m & ~d).sum() / max((m | ~d).sum(), 1))
+            print("%5d^2 x%d %-40s %s  median %.2f us   kernel %s   |u|<32: %.4f of the pixels, max|u| %.2f, mask IoU vs disk %.5f" % (
+                n, C_, label, " ".join("%.2f" % v for v in t), np.median(t), ctx.launch_info()["kernel"], (np.abs(u) < 32).mean(), np.abs(u).max(), iou), flush=True)
