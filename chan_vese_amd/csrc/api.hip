@@ -37,8 +37,8 @@ struct cvh_context {
   double stop_cond_h = 0.0; // tol * stop_norm of the current run (a launch argument)
   int math_mode = CVH_MATH_DEFAULT, finalize_mode = 0, sync_every = 32;
   int tile_rows = 0 /* auto */, use_lut = 1, use_dma = 0;
-  int kernel = -1;      // -1 auto, 0 tile kernel, 1 strip kernel, 2 wave kernel
-  int pm_kernel = -1;   // -1 auto, 0 tile kernel, 1 wave kernel, 2 wave kernel with 2 pixels per lane
+  int kernel = -1;      // -1 auto, 0 tile kernel, 2 wave kernel, 3 wave kernel with 2 pixels per lane
+  int pm_kernel = -1;   // -1 auto (4 where the plane and the run qualify, else 3), 0 tile kernel, 1 wave kernel, 3 two time steps per launch, 4 resident plane
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = -1 /* auto: 1 channel 1, 3 channels 0 */, wave_imgv = 1, wave_depth = 4;
   int near_switch = 1;  // option "near_switch": per-wave, per-group choice of the form of H_eps (csv_wave2_kernel.hip); 0 = far form + correction always
@@ -314,12 +314,12 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (value != 0 && value != 12 && value != 14 && value != 16) return fail(c, CVH_ERR_ARG, "tile_rows must be 0 (auto), 12, 14 or 16");
     c->tile_rows = (int)value;
   } else if (!strcmp(key, "kernel")) {
-    if (value < -1 || value > 3) return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile), 1 (strip), 2 (wave) or 3 (wave, 2 pixels per lane)");
-    if (value == 1 && (c->w % 16) != 0) return fail(c, CVH_ERR_ARG, "the strip kernel needs a width that is a multiple of 16");
+    if (value < -1 || value > 3 || value == 1)      // (1 was the strip kernel of round 1: never chosen, no fallback -- tools/experiments/pruned_flavours/)
+      return fail(c, CVH_ERR_ARG, "kernel must be -1 (auto), 0 (tile), 2 (wave) or 3 (wave, 2 pixels per lane)");
     c->kernel = (int)value;
   } else if (!strcmp(key, "pm_kernel")) {
-    if (value < -1 || value > 4)
-      return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave), 2 (wave, 2 pixels per lane), 3 (wave, 2 time steps per launch) or 4 (resident plane)");
+    if (value < -1 || value > 4 || value == 2)     // (2 was a 2-pixel-per-lane 1-step kernel: never chosen -- tools/experiments/pruned_flavours/)
+      return fail(c, CVH_ERR_ARG, "pm_kernel must be -1 (auto), 0 (tile), 1 (wave), 3 (wave, 2 time steps per launch) or 4 (resident plane)");
     c->pm_kernel = (int)value;
   } else if (!strcmp(key, "res_straight")) {
     c->res_straight = value ? 1 : 0;
@@ -575,12 +575,11 @@ extern "C" int cvh_get_levelset(cvh_context *c, double *u)
 
 struct Geometry { int strip; int rows; int tiles_x, tiles_y, strip_rows, nblocks; };
 
-// Which step kernel runs and on what grid.  The strip kernel (16-byte pieces) needs
-// w % 16 == 0; its grid is one balanced round of resident workgroups.
+// Which step kernel runs and on what grid (g.strip: 0 tile kernel, 2 wave kernel, 3 wave kernel with 2 pixels per lane).
 static Geometry resolve_geometry(const cvh_context *c)
 {
   Geometry g;
-  g.strip = c->kernel == 1;
+  g.strip = 0;
   // default: the wave kernel (any width; fastest measured); it addresses the level set through
   // buffer instructions with 32-bit byte offsets and marks dropped lanes with offset 2^31, so
   // images of 2^28 pixels (2 GiB of level set) or more use the tile kernel
@@ -648,24 +647,9 @@ static Geometry resolve_geometry(const cvh_context *c)
     g.nblocks = ((g.tiles_x + 3) / 4) * g.tiles_y;  // 4 adjacent wave-columns per workgroup
     return g;
   }
-  if (g.strip) {
-    g.rows = c->tile_rows == 12 ? 12 : 16;
-    g.tiles_x = (c->w + 255) / 256;
-    int sr = c->strip_rows;
-    if (sr <= 0) {
-      const int per_cu = 4;  // measured best on MI355X at 4096^2 (profiles/README.md)
-      int nseg = (c->num_cus * per_cu) / g.tiles_x;
-      if (nseg < 1) nseg = 1;
-      sr = (c->h + nseg - 1) / nseg;
-    }
-    sr = ((sr + g.rows - 1) / g.rows) * g.rows;
-    g.strip_rows = sr;
-    g.tiles_y = (c->h + sr - 1) / sr;
-  } else {
-    g.rows = c->tile_rows == 16 ? 16 : 14;  // auto = 14: keeps 4 workgroups per CU beside the tables
-    cvh_step_grid(c->h, c->w, g.rows, &g.tiles_x, &g.tiles_y);
-    g.strip_rows = g.rows;
-  }
+  g.rows = c->tile_rows == 16 ? 16 : 14;  // auto = 14: keeps 4 workgroups per CU beside the tables
+  cvh_step_grid(c->h, c->w, g.rows, &g.tiles_x, &g.tiles_y);
+  g.strip_rows = g.rows;
   g.nblocks = g.tiles_x * g.tiles_y;
   return g;
 }
@@ -951,7 +935,6 @@ static int launch_one_step(cvh_context *c, int in_buf, int step, bool capturing 
   const int kind = resolve_geometry(c).strip;
   if (kind == 3) HIPCHK(c, cvh_launch_wave2(a, c->C, use_fast(c), c->stream));
   else if (kind == 2) HIPCHK(c, cvh_launch_wave(a, c->C, use_fast(c), c->stream));
-  else if (kind == 1) HIPCHK(c, cvh_launch_strip(a, c->C, use_fast(c), c->stream));
   else HIPCHK(c, cvh_launch_step(a, c->C, use_fast(c), c->stream));
   if (note) return CVH_OK;
   if (c->finalize_mode == 1) HIPCHK(c, cvh_launch_finalize(a, c->C, 0, c->stream));
@@ -1410,14 +1393,11 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
     if (c->pm_kernel == 4 && trips > 0)
       return fail(c, CVH_ERR_ARG, "pm_kernel 4 (resident plane) needs an even width, >= 16 rows and columns, and a plane that fits the LDS of the CUs");
   }
-  // auto: the 2-pixel kernel for large planes (measured 50.4 vs 53.3 us/step at 4096^2, but 19 vs 15.7 at 2048^2:
-  // its strips get too short there), the 1-pixel wave kernel otherwise
-  const bool pm2_ok = c->w % 2 == 0 && c->w >= 128 && c->n < ((size_t)1 << 28);
-  const bool pm_wave2 = pm2_ok && c->pm_kernel == 2;   // (was the default from 12 Mpixel on: 48.4 us/step at 4096^2; the 2-step kernel: 39.3)
   // two time steps per launch (pm_wave_k2_kernel.hip): planes that fit the caches, where a step is launch / latency bound
-  const bool pm_k2 = !pm_wave2 && trips >= 2 && c->n < ((size_t)1 << 28) &&
-                     (c->pm_kernel == 3 || c->pm_kernel == -1);
-  const bool pm_wave = !pm_wave2 && c->pm_kernel != 0;
+  // (a 2-pixel-per-lane 1-step kernel was the default from 12 Mpixel on in round 1: 48.4 us/step at 4096^2 against 39.3 for the 2-step
+  // kernel -- tools/experiments/pruned_flavours/pm_wave2_kernel.hip)
+  const bool pm_k2 = trips >= 2 && c->n < ((size_t)1 << 28) && (c->pm_kernel == 3 || c->pm_kernel == -1);
+  const bool pm_wave = c->pm_kernel != 0;
   CvhPmArgs a2 = a;      // geometry of the 2-step kernel (the odd last step runs the 1-step wave kernel)
   if (pm_k2) {
     a2.tiles_x = (c->w + cvh_pm_wave_k2_cols() - 1) / cvh_pm_wave_k2_cols();
@@ -1431,19 +1411,7 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
     }
     a2.strip_rows = sr;
   }
-  if (pm_wave2) {   // 2 pixels per lane: 124 output columns per wave, workgroup = 2 wave-columns x 2 strips
-    a.tiles_x = (c->w + cvh_pm_wave2_cols() - 1) / cvh_pm_wave2_cols();
-    int sr = c->pm_strip_rows;
-    if (sr <= 0) {
-      const int nbc = (a.tiles_x + 1) / 2;
-      int nstrips = 2 * ((c->num_cus * 3) / nbc);   // ~3 waves per SIMD resident
-      if (nstrips < 1) nstrips = 1;
-      sr = (c->h + nstrips - 1) / nstrips;
-      sr = ((sr + 3) / 4) * 4;
-      if (sr < 8) sr = 8;
-    }
-    a.strip_rows = sr;
-  } else if (pm_wave) {
+  if (pm_wave) {
     a.tiles_x = (c->w + cvh_pm_wave_cols() - 1) / cvh_pm_wave_cols();
     int sr = c->pm_strip_rows;
     if (sr <= 0) {  // ~3 waves per SIMD resident
@@ -1457,9 +1425,9 @@ extern "C" int cvh_perona_malik(cvh_context *c, double K, double L, double T)
   } else {
     cvh_pm_grid(c->h, c->w, &a.tiles_x, &a.tiles_y);
   }
-  const int kind = pm_wave2 ? 2 : (pm_wave ? 1 : 0);
+  const int kind = pm_wave ? 1 : 0;
   auto launch_pm = [&](const CvhPmArgs &pa) -> hipError_t {
-    return kind == 2 ? cvh_launch_pm_wave2(pa, c->stream) : (kind == 1 ? cvh_launch_pm_wave(pa, c->stream) : cvh_launch_pm_step(pa, c->stream));
+    return pm_wave ? cvh_launch_pm_wave(pa, c->stream) : cvh_launch_pm_step(pa, c->stream);
   };
   const int per_launch = pm_k2 ? 2 : 1;   // time steps per launch of the bulk kernel
   auto launch_bulk = [&](int from, CvhLaunchNote *note = nullptr) -> hipError_t {

@@ -12,15 +12,6 @@ namespace cvh_dev {
 // (An `if (lane_valid)` store is a control-flow diamond; a store hidden in inline assembly is not
 // counted, and every counted wait then also drains the stores and the younger loads: measured,
 // waves spent 50 % of their cycles in s_waitcnt -- profiles/README.md.)
-#ifndef CVH_LOAD_AUX
-#define CVH_LOAD_AUX 0
-#endif
-#ifndef CVH_LOADI_AUX
-#define CVH_LOADI_AUX 0
-#endif
-#ifndef CVH_STORE_AUX
-#define CVH_STORE_AUX 0
-#endif
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0x80000000u;   // beyond any buffer this kernel accepts (< 2 GiB)
@@ -29,31 +20,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000 /* raw, 32-bit data format (gfx950) */);
 }
-// Diagnostic builds (tools/abl_bench.sh; results are wrong by design): -DCVH_ABLATE_MEMORY replaces every
-// global load of the march by two integer instructions and drops the stores; -DCVH_ABLATE_COMPUTE keeps
-// the memory and LDS traffic and drops the arithmetic of a row.
+// (The ablation builds of round 2 -- every global load of the march replaced by two integer instructions and the stores dropped, or the
+// arithmetic of a row dropped with every load, LDS exchange and store kept: 42-46 / 53.5-54.6 us against 59-60.7 us for the full kernel
+// at 4096^2 -- are a patch under tools/experiments/pruned_flavours/ now, not macros in the shipped sources.)
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-#ifdef CVH_ABLATE_MEMORY
-  return __builtin_bit_cast(double, 0x4000000000000000ull | (unsigned long long)(voff + soff));
-#else
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, CVH_LOAD_AUX));
-#endif
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 __device__ __forceinline__ u32x4_t buf_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-#ifdef CVH_ABLATE_MEMORY
-  const unsigned v = (voff + soff) * 0x9e3779b1u;
-  return u32x4_t{v, v ^ 0x55aa55aau, v + 0x01020304u, v};
-#else
-  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CVH_LOADI_AUX);
-#endif
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
 __device__ __forceinline__ void buf_store_f64(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-#ifndef CVH_ABLATE_MEMORY
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, CVH_STORE_AUX);
-#endif
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
 }
 
 

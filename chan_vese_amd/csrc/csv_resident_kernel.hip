@@ -39,16 +39,10 @@ namespace {
 constexpr int RT_W = 128;                 // tile width: 64 lanes x 2 pixels
 constexpr int RT_HMAX = 128;              // most rows a tile may have (LDS)
 constexpr int RT_PITCH = 132;             // doubles per LDS row: tile columns -2 .. 129
-#ifndef CVH_RES_MSLEEP
-#define CVH_RES_MSLEEP 1                  // s_sleep between the master's polls of the arrival lines (A/B builds)
-#endif
-#ifndef CVH_RES_GSLEEP
-#define CVH_RES_GSLEEP 3                  // s_sleep between a workgroup's polls of its release line (A/B builds)
-#endif
-#ifndef CVH_RT_WAVES
-#define CVH_RT_WAVES 8                    // waves per workgroup (A/B builds: 16 = 4 per SIMD at <= 128 VGPRs)
-#endif
-constexpr int RT_WAVES = CVH_RT_WAVES, RT_THREADS = 64 * RT_WAVES;
+// Poll cadences and waves per workgroup were A/B build macros in round 3 (profiles/r03_C4/resident_poll_variants.txt: s_sleep 1 between the
+// master's polls and 3 between a workgroup's polls of its release line are a local optimum; 12 / 16 waves per workgroup: 17.4 / 33 us).
+constexpr int kMasterSleep = 1, kReleaseSleep = 3;
+constexpr int RT_WAVES = 8, RT_THREADS = 64 * RT_WAVES;
 constexpr int RT_HALO = 6 * RT_W;         // doubles a tile publishes per iteration: bottom 2 rows, top row, right 2 columns, left column
 
 
@@ -130,7 +124,7 @@ __device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int ge
       const u32x4r_t ga = ld_line16(rs->go, (unsigned)bid * 64u), gb = ld_line16(rs->go, (unsigned)bid * 64u + 16u);
       if (ga.x == gb.x && ga.x >= (unsigned)gen && ga.x != 0xffffffffu) { res = (int)(ga.y & 1u); m1 = line16_f64(ga); m2 = line16_f64(gb); break; }
       if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(CVH_RES_GSLEEP);
+      if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(kReleaseSleep);
     }
     if (res < 0) st_agent(const_cast<int *>(&rs->error), 1);
     s_bc[0] = (double)res; s_bc[1] = m1; s_bc[2] = m2;
@@ -299,7 +293,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       // the contour are corrected per group of four rows (csv_wave2_kernel.hip, DEFER)
       double2_t keep[4];
       int smp_keep[4];
-      unsigned long long near_any = 0ull;   // lanes below the far-field threshold in the current group of rows (one mask, not four)
+      unsigned long long near_mask[4];       // lanes below the far-field threshold, per row of the current group (csv_wave2_kernel.hip: four independent masks are the fastest form)
       // (no branch inside a row: a group of four rows is one basic block and hipcc overlaps the rows' dependent chains)
       // (rel = row inside the band: a constant in the straight-line flavours, where every address below is base + immediate)
       double *const pb = S(rb0, ca);
@@ -341,7 +335,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         *reinterpret_cast<double2_t *>(pb + rel * RT_PITCH) = keep[k];
         if (!NEARFORM) {
           const double hva = heaviside_centred_far(va, fc), hvb = heaviside_centred_far(vb, fc);
-          near_any |= __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
+          near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
           acc[0] += hva; acc[0] += hvb;
           acc[2] = __builtin_fma(Ia, hva, acc[2]); acc[2] = __builtin_fma(Ib, hvb, acc[2]);
         }
@@ -350,7 +344,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       };
       auto correct = [&](int k, auto near_tag) {
         constexpr bool NEARFORM = decltype(near_tag)::value;
-        if (NEARFORM || __builtin_amdgcn_ballot_w64(fabs(keep[k].x) < fc.thr || fabs(keep[k].y) < fc.thr) != 0ull) {
+        if (NEARFORM || near_mask[k] != 0ull) {
           const double xa = keep[k].x, xb = keep[k].y;
           double da, db;
           if (NEARFORM) {   // the rows added nothing for H
@@ -371,11 +365,10 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
           for (int g = 0; g < NRT / 4; ++g) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) row(4 * g + k, k, near_tag);
-            if (NEARFORM || near_any != 0ull) {
+            if (NEARFORM || (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) correct(k, near_tag);
             }
-            near_any = 0ull;
           }
         } else if (NRT == 2) {
           row(0, 0, near_tag); correct(0, near_tag);
@@ -385,11 +378,10 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
           for (; rel + 4 <= rb1 - rb0; rel += 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) row(rel + k, k, near_tag);
-            if (NEARFORM || near_any != 0ull) {
+            if (NEARFORM || (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) correct(k, near_tag);
             }
-            near_any = 0ull;
           }
           for (; rel < rb1 - rb0; ++rel) { row(rel, 0, near_tag); correct(0, near_tag); }
         }
@@ -451,7 +443,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         const bool ok = !have || (fa.x >= gen && fa.x != 0xffffffffu && (lane >= 32 || (fb.x >= gen && fb.x != 0xffffffffu)));
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { done = true; break; }
         if ((round & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-        __builtin_amdgcn_s_sleep(CVH_RES_MSLEEP);
+        __builtin_amdgcn_s_sleep(kMasterSleep);
       }
       if (done) {
         const double ws = wave_sum((have && lane < 32) ? line16_f64(fa) : 0.0);                       // fixed order: lane = tile

@@ -14,8 +14,8 @@
 // quads).  Requires w % 16 == 0 and w >= 144 (16-byte image pieces); other shapes use kernel 2.
 // C = 3 (round 3, FAST only): one image tile per channel (two piece loads per group), the samples are read from the
 // tile inside the row (no per-group sample registers), and the region term sum_k [l2k (I_k - c2k)^2 - l1k (I_k - c1k)^2] beta
-// + gamma is either three table lookups (POLY false) or, with POLY, the quadratic sum_k (qa_k I_k + qb_k) I_k + qc with
-// seven wave-uniform coefficients -- no table fill, no 16-byte LDS returns (rounding moves by a few ulp of the term)
+// + gamma is three table lookups.  (The table-free quadratic form sum_k (qa_k I_k + qb_k) I_k + qc of round 3 -- 81 against 72 us --
+// lives in tools/experiments/pruned_flavours/.)
 #include "csv_device.h"
 #include "buffer_ops.h"
 #include "wave_math.h"
@@ -27,12 +27,12 @@ using namespace cvh_dev;
 
 namespace {
 
-template <int C, bool FAST, int MINW, int POL, bool POLY>
+template <int C, bool FAST, int MINW, int POL>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhStepArgs a)
 {
   static_assert(C == 1 || FAST, "the 3-channel flavour exists in FAST arithmetic only (STRICT: kernel 2)");
-  static_assert(!POLY || C == 3, "POLY is the 3-channel region term");
-  using L = Wave2Smem<FAST, C, !POLY>;
+  static_assert(FAST ? MINW == 3 : MINW == 2, "compiled for 3 waves per SIMD (FAST: branch-free rows) or 2 (STRICT)");
+  using L = Wave2Smem<FAST, C>;
   constexpr int NS = cvh_nsums(C), R = R2;
   constexpr int NIQ = (9 * R * C + 63) / 64;   // image piece loads per group (9 pieces x R rows x C channels, one lane each)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   // lane, in flight beside the first rows of u) or from the state block the last finaliser wrote
   double c1, c2;
   double cm1[C], cm2[C];                    // C = 3: the region means per channel
-  double qa[C], qb[C], qc = 0.0;            // POLY: coefficients of the quadratic region term (wave-uniform)
   long long chain_entry = 0;
   if (chain) chain_entry = a.chain->v[a.chain_phase][lane];
   else if (C == 1) { c1 = a.st->c1[0]; c2 = a.st->c2[0]; }
@@ -120,18 +119,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     } else {
       if (chain) chain_means<C>(a, chain_entry, cm1, cm2);
       for (int q = tid; q < CVH_ATAN2_N; q += CVH_BLOCK) satan[q] = a.atan2_tab[q];
-      if (POLY) {
-        // sum_k [l2k (I - c2k)^2 - l1k (I - c1k)^2] beta + gamma = sum_k (qa_k I + qb_k) I + qc   (:307-310, :979, :985)
-        qc = a.gamma;
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const double k1 = a.lambda1[k], k2 = a.lambda2[k];
-          qa[k] = read_lane((k2 - k1) * a.beta, 0);
-          qb[k] = read_lane(-2.0 * a.beta * (k2 * cm2[k] - k1 * cm1[k]), 0);
-          qc = __builtin_fma(a.beta, k2 * cm2[k] * cm2[k] - k1 * cm1[k] * cm1[k], qc);
-        }
-        qc = read_lane(qc, 0);
-      } else {
+      {
 #pragma unroll
         for (int k = 0; k < C; ++k) {
           const double v = (double)tid;
@@ -317,14 +305,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       const double ny = norm(s_, n_, c);
       const double kappa = __builtin_fma(nx - nxl, fx, ny - nyp);
       double reg;
-      if (POLY) {
-        reg = qc;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          Ik[ch] = (double)(byte[ch] >> 4);
-          reg = __builtin_fma(__builtin_fma(qa[ch], Ik[ch], qb[ch]), Ik[ch], reg);
-        }
-      } else {
+      {
         const double2_t e0 = lds_read_d2(kLutAddr + (unsigned)byte[0]);   // `byte[ch]` is the entry's byte offset inside channel ch's table (sample x 16)
         reg = e0.x; Ik[0] = e0.y;
 #pragma unroll
@@ -343,10 +324,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       return c + ud;                                                   // :994
     };
 
-    // DEFER (3 waves/SIMD: register room): rows without a branch, see csv_wave_kernel.hip
-    constexpr bool DEFER = FAST && MINW <= 3;
+    // DEFER (FAST, 3 waves/SIMD: register room): rows without a branch, see csv_wave_kernel.hip
+    constexpr bool DEFER = FAST;
     double2_t keep[R];
-    unsigned long long near_any = 0ull;   // lanes that met a pixel below the far-field threshold in this group's rows (ONE mask: four would spill SGPRs into VGPRs)
+    // lanes that met a pixel below the far-field threshold, per row of the group.  (Measured, round 4, one process: ONE mask OR-ed up row by
+    // row costs 3 us per 4096^2 launch -- the rows' dependent chains no longer overlap --, one running minimum of |u| per lane 0.7 us;
+    // four independent masks, two of which hipcc parks in VGPRs, are the fastest form.)
+    unsigned long long near_mask[R];
     int smp3[C][R];   // NEARFORM, three channels: the group's samples, taken aside before the park refills the image tile
     auto row = [&](int i, int k, bool live, auto near_tag) {
       constexpr bool NEARFORM = decltype(near_tag)::value;   // this group evaluates H_eps in its table form on every lane (below)
@@ -364,15 +348,6 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
         for (int ch = 0; ch < C; ++ch) { const unsigned s = (unsigned)samples(ch, k); sa[ch] = (int)byte_x16<0>(s); sb[ch] = (int)byte_x16<1>(s); }
       }
       const int ba = sa[0], bb = sb[0];
-#ifdef CVH_ABLATE_COMPUTE
-      {   // keeps every load, LDS exchange and the store; no arithmetic
-        keep[k] = double2_t{u0.x + (up.x + um.x + uw) * 1e-30 + (double)(ba >> 4) * 1e-30, u0.y + (up.y + um.y + ue) * 1e-30 + (double)(bb >> 4) * 1e-30};
-        buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
-        acc[0] += keep[k].x; acc[4] += 1.0;   // a non-zero norm: the stop rule must not fire
-        um = u0; u0 = up; uw = uw_n; ue = ue_n;
-        return;
-      }
-#endif
       // x-gradients first: nx(b) is the west gradient of lane+1's a (DPP), nx(a) the west gradient of b
       const double nxa = norm(u0.y, uw, u0.x);       // east = own b, west = lane-1's b
       const double nxb = norm(ue, u0.x, u0.y);       // east = lane+1's a, west = own a
@@ -398,15 +373,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       keep[k] = double2_t{va, vb};
       if (FAST && DEFER && NEARFORM) {   // H_eps of the whole group is taken behind its rows, in the table form (group())
         hva = 0.0; hvb = 0.0;
+        near_mask[k] = 0ull;
       } else if (FAST && DEFER) {   // far-field form on every lane; near lanes are corrected once per group (no branch in a row)
         hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
-        near_any |= __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
-      } else if (FAST) {   // far/near decided per WAVE for both pixels (uniform branch)
-        if (__builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr) == 0ull) {
-          hva = heaviside_centred_far(va, fc); hvb = heaviside_centred_far(vb, fc);
-        } else {
-          hva = heaviside_centred_near(va, a.inv_eps, satan); hvb = heaviside_centred_near(vb, a.inv_eps, satan);
-        }
+        near_mask[k] = __builtin_amdgcn_ballot_w64(fabs(va) < fc.thr || fabs(vb) < fc.thr);
       } else {
         hva = heaviside_strict(va, eps); hvb = heaviside_strict(vb, eps);
       }
@@ -473,9 +443,9 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         if (INTERIOR || (ib + k) < s1) row(ib + k, k, true, near_tag);   // wave-uniform: rows past the strip end cost nothing
+        else near_mask[k] = 0ull;
       }
-      const bool any_near = near_any != 0ull;
-      near_any = 0ull;
+      const bool any_near = DEFER && !NEARFORM && (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull;
       // H_eps - 1/2 of row k's pair from keep[k]: TABLE true = the table form of every pixel (the rows of a NEARFORM group added nothing for H),
       // else the per-group correction of the lanes below the far-field threshold (the rows added the far form on every lane)
       auto finish_row = [&](int k, int smp0, auto table_tag) {
@@ -504,8 +474,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       if (DEFER && !NEARFORM && any_near) {
 #pragma unroll
         for (int k = 0; k < R; ++k)
-          if ((INTERIOR || (ib + k) < s1) &&        // (which rows: asked again here, on the rare path, instead of keeping four masks)
-              __builtin_amdgcn_ballot_w64(fabs(keep[k].x) < fc.thr || fabs(keep[k].y) < fc.thr) != 0ull) finish_row(k, im[k], std::false_type{});
+          if (near_mask[k] != 0ull && (INTERIOR || (ib + k) < s1)) finish_row(k, im[k], std::false_type{});
       }
       if (DEFER && NEARFORM) {
         // the table forms come BEHIND the park: the prefetched rows (22 registers) are in the ring by then, and the forms of eight pixels
@@ -575,14 +544,13 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   if (a.dbg_times && tid == 0) a.dbg_times[(size_t)a.nparts * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int C, bool FAST, int MINW, int POL, bool POLY = false>
+template <int C, bool FAST, int MINW, int POL>
 hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 {
-  using L = Wave2Smem<FAST, C, !POLY>;
+  using L = Wave2Smem<FAST, C>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup
-  CVH_LAUNCH((csv_wave2_kernel<C, FAST, MINW, POL, POLY>), a.nparts + extra, L::bytes, s, a, "csv_wave2_kernel<%d, %s, %d, %d, %s>", C,
-             CVH_TF(FAST), MINW, POL, CVH_TF(POLY));
+  CVH_LAUNCH((csv_wave2_kernel<C, FAST, MINW, POL>), a.nparts + extra, L::bytes, s, a, "csv_wave2_kernel<%d, %s, %d, %d>", C, CVH_TF(FAST), MINW, POL);
   return hipGetLastError();
 }
 
@@ -590,15 +558,14 @@ hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 
 int cvh_wave2_cols() { return W2; }
 
+// Instantiations: <1, false, 2, 1> STRICT; <1, true, 3, POL> and <3, true, 3, POL> FAST with the cache policy of the rows as a template
+// parameter (wave2_device.h: 1 write-through stores + sc0 loads, 0 plain, 2 plain stores + non-temporal loads -- diagnostic).  Round 3
+// also shipped a 4-waves/SIMD flavour (95.7 against 57.3 us at 4096^2) and a table-free 3-channel region term (81 against 72 us): neither
+// was ever chosen, neither is a fallback -- tools/experiments/pruned_flavours/README.md.
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s)
 {
-  if (channels == 3) {   // FAST only (api.hip routes STRICT to kernel 2); use_lut = 0 selects the quadratic region term
-    if (a.use_lut) return a.wave_pol ? launch_wave2<3, true, 3, 1, false>(a, s) : launch_wave2<3, true, 3, 0, false>(a, s);
-    return a.wave_pol ? launch_wave2<3, true, 3, 1, true>(a, s) : launch_wave2<3, true, 3, 0, true>(a, s);
-  }
+  if (channels == 3) return a.wave_pol ? launch_wave2<3, true, 3, 1>(a, s) : launch_wave2<3, true, 3, 0>(a, s);   // FAST only (api.hip routes STRICT to kernel 2)
   if (!fast) return launch_wave2<1, false, 2, 1>(a, s);
-  // default: 3 waves/SIMD with branch-free rows (measured 65.1 vs 66.3 us for 4 waves/SIMD with the per-row branch)
-  if (a.wave_minw == 4) return launch_wave2<1, true, 4, 1>(a, s);
-  if (a.wave_pol == 2) return launch_wave2<1, true, 3, 2>(a, s);   // diagnostic: plain stores, non-temporal loads
-  return a.wave_pol ? launch_wave2<1, true, 3, 1>(a, s) : launch_wave2<1, true, 3, 0>(a, s);   // cache policy of the rows: wave2_device.h
+  if (a.wave_pol == 2) return launch_wave2<1, true, 3, 2>(a, s);
+  return a.wave_pol ? launch_wave2<1, true, 3, 1>(a, s) : launch_wave2<1, true, 3, 0>(a, s);
 }

@@ -284,15 +284,6 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave_kernel(const CvhStep
       // row i+1 (own column and its x-neighbours, the latter for the next step) from ring slot k
       const double up = x_own[k * XPITCH];
       const double uw_n = x_w[k * XPITCH], ue_n = x_e[k * XPITCH];
-#ifdef CVH_ABLATE_COMPUTE
-      if (FAST) {
-        const double un_ = u0 + (up + um + uw + ue) * 1e-30 + (double)im[0][k] * 1e-30;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, un_), make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes, POL ? 16 : 0);
-        acc[0] += un_;
-        um = u0; u0 = up; uw = uw_n; ue = ue_n;
-        return;
-      }
-#endif
       double nx, ny;
       if (FAST) {
         const double u02 = u0 + u0;

@@ -10,7 +10,7 @@
 #define CVH_BLOCK 256  // 4 waves of 64
 
 // Ablation / diagnostic keys of cvh_set_option (not part of include/chanvese_hip.h; defaults are what ships):
-//   "wave_occupancy" waves per SIMD the wave kernels' grid is sized for (3..5; kernel 2: 5, kernel 3: 3),
+//   "wave_occupancy" waves per SIMD the 1-pixel wave kernel's grid is sized for (3..5; default 5; the 2-pixel kernel is built for 3),
 //   "wave_depth" rows per group (4, 8), "wave_prio" s_setprio progress equalisation (0 off, 1 quarters,
 //   2-4 thresholds crowded to the end, 5 clock-paced), "wave_sync" workgroup barrier per group (1),
 //   "wave_imgv" 16-byte image pieces (1), "wave_xcd" XCD-contiguous workgroup numbering (1),
@@ -167,7 +167,6 @@ struct CvhPmArgs {
 void cvh_step_grid(int h, int w, int tile_rows, int *tiles_x, int *tiles_y);
 int cvh_step_max_blocks(int h, int w);
 hipError_t cvh_launch_step(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
-hipError_t cvh_launch_strip(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 int cvh_wave2_cols();
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s);
 hipError_t cvh_launch_chain_flush(const CvhStepArgs &a, int channels, hipStream_t s);
@@ -190,8 +189,6 @@ int cvh_init_sum_blocks(int h, int w);
 
 hipError_t cvh_launch_pm_load(const uint8_t *plane, double *state, size_t n, hipStream_t s);
 hipError_t cvh_launch_pm_step(const CvhPmArgs &a, hipStream_t s);
-int cvh_pm_wave2_cols();
-hipError_t cvh_launch_pm_wave2(const CvhPmArgs &a, hipStream_t s);
 hipError_t cvh_launch_pm_wave(const CvhPmArgs &a, hipStream_t s);
 int cvh_pm_wave_k2_cols();
 hipError_t cvh_launch_pm_wave_k2(const CvhPmArgs &a, hipStream_t s);   // TWO time steps per launch

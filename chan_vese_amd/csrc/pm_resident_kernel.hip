@@ -43,9 +43,7 @@ constexpr int PT_HALO = 8 * PT_W;         // doubles a tile publishes per step: 
 constexpr int PT_RING = 4 * PT_PITCH + 4 * PT_HMAX;          // cells of the halo ring (rows -2, -1, TH, TH+1; columns -2, -1, TW, TW+1)
 constexpr int PT_GATHER = (PT_RING + PT_THREADS - 1) / PT_THREADS;   // ring cells per thread
 
-#ifndef CVH_PMR_SB
-#define CVH_PMR_SB 1                      // scheduling barrier behind every (CVH_PMR_SB + 1)-th row of the march (A/B builds: 0, 3, 1023)
-#endif
+constexpr int kRowsPerSched = 2;          // a scheduling barrier behind every second row of the march (round 3, pm_sched_variants.txt: 1, 4 or no barrier: no faster, more registers)
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
         h0 = hp; hp = hpp;
         g0a = gpa; g0b = gpb;
         vda = vna; vdb = vnb; gsa = gna; gsb = gnb;
-        if ((k & CVH_PMR_SB) == CVH_PMR_SB) __builtin_amdgcn_sched_barrier(0);      // CVH_PMR_SB + 1 rows at a time may be interleaved, not more (registers)
+        if (k % kRowsPerSched == kRowsPerSched - 1) __builtin_amdgcn_sched_barrier(0);   // two rows at a time may be interleaved, not more (registers)
       }
     }
     // ---- the top / bottom two rows of a full tile straight from the registers: the stores travel while the workgroup meets

@@ -12,9 +12,8 @@ constexpr int R2 = 4;        // rows per group = ring slots
 constexpr int IMGP2 = 144;   // bytes per row of the per-wave image tile (9 x 16-byte pieces)
 constexpr int NS2 = cvh_nsums(1);
 
-// C channels: one image tile per channel; LUT = the region term as a 256-entry table per channel (LUT false: the
-// 3-channel flavour evaluates it as a quadratic in the sample, wave2 kernel POLY)
-template <bool FAST, int C = 1, bool LUT = true>
+// C channels: one image tile per channel; the region term is a 256-entry table per channel
+template <bool FAST, int C = 1>
 struct Wave2Smem {
   static constexpr int NS = cvh_nsums(C);
   static constexpr int wave_doubles = R2 * XP2 + 64 + C * R2 * IMGP2 / 8; // ring + scratch + image tiles
@@ -22,8 +21,8 @@ struct Wave2Smem {
   static constexpr int off_red = off_x + 4 * wave_doubles;                // 4*NS
   static constexpr int off_fin = off_red + 4 * NS + (4 * NS) % 2;         // NS (+1 pad)
   static constexpr int off_atan = off_fin + NS + NS % 2;                  // FAST: CVH_ATAN2_N
-  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // FAST && LUT: C x 256 x {term, I}
-  static constexpr int off_flag = off_lut + (FAST && LUT ? C * 512 : 0);
+  static constexpr int off_lut = (off_atan + (FAST ? CVH_ATAN2_N + 1 : 0) + 1) & ~1;  // FAST: C x 256 x {term, I}
+  static constexpr int off_flag = off_lut + (FAST ? C * 512 : 0);
   static constexpr int doubles = off_flag + 2;
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
@@ -33,31 +32,15 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // dirty lines pile up in the XCD's L2) and loads sc0 -- faster while the ping-pong pair (mostly) fits the 256 MiB Infinity Cache
 // (2048^2: 20.9 vs 22.1 us; 4096^2: 0..-1.3 us); POL 0: plain -- faster beyond it (4608^2: 80.6 vs 85.2 us; 5120^2: 100.5 vs 110.2 us).
 // The host picks by footprint (api.hip, fill_args); nt stores +1.6 us, sc1 loads +0.5 us at 4096^2.
-// (-DCVH_ABLATE_MEMORY / -DCVH_ABLATE_COMPUTE: diagnostic builds, results wrong by design -- see buffer_ops.h)
-#ifndef CVH_POL0_LOAD_AUX
-#define CVH_POL0_LOAD_AUX 0    // A/B builds (tools/build_variant.sh)
-#endif
-#ifndef CVH_POL0_STORE_AUX
-#define CVH_POL0_STORE_AUX 0
-#endif
 template <int POL>
 __device__ __forceinline__ double2_t buf_load_f64x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-#ifdef CVH_ABLATE_MEMORY
-  const double v = __builtin_bit_cast(double, 0x4059000000000000ull | (unsigned long long)((voff + soff) & 0xffff));   // ~100: far field
-  return double2_t{v, -v};
-#else
-  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL == 1 ? 1 : (POL == 2 ? 2 : CVH_POL0_LOAD_AUX)));   // POL 2 (diagnostic): nt loads
-#endif
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL == 1 ? 1 : (POL == 2 ? 2 : 0)));   // POL 2 (diagnostic): nt loads
 }
 template <int POL>
 __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-#ifndef CVH_ABLATE_MEMORY
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL == 1 ? 16 : CVH_POL0_STORE_AUX);
-#else
-  asm volatile("" :: "v"(v.x), "v"(v.y));
-#endif
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL == 1 ? 16 : 0);
 }
 
 }  // namespace cvh_dev

@@ -85,20 +85,13 @@ __device__ __forceinline__ double heaviside_centred_near(double u, double inv_ep
 __device__ __forceinline__ double normalised4(double fwd, double bwd, double centre2)
 {
   const double a = __builtin_fma(fwd, 2.0, -centre2), d = fwd - bwd;
-#ifdef CVH_RSQ_NEWTON
-  // A/B build: hardware estimate + ONE Newton step folded into the product (one FP64 operation less per call, ~2^-46)
-  const double s = __builtin_fma(a, a, __builtin_fma(d, d, 4.0 * kEta2));
-  const double r = __builtin_amdgcn_rsq(s);
-  const double e = __builtin_fma(-(s * r), r, 1.0);
-  const double ar = a * r;
-  return __builtin_fma(ar * e, 0.5, ar);
-#else
   return a * rsqrt_refined(__builtin_fma(a, a, __builtin_fma(d, d, 4.0 * kEta2)));
-#endif
 }
 
 // Byte BYTE (0 or 1) of `word` times 16 -- the byte offset of a 16-byte {term, sample} table entry -- in ONE instruction: an SDWA
-// operand select on the shift (hipcc emits v_and / v_bfe + v_lshl_add: two).  The kernels are bound by the instructions a wave issues.
+// operand select on the shift (hipcc emits v_and / v_bfe + v_lshl_add: two).  With lds_read_d2 below the hot path of a group of four rows
+// is 475 instead of 490 instructions (three channels: 558 instead of 581) -- measured in one process against builds without either
+// (round 4, gpurun_out/r4s5, r4s6): no difference beyond the +-0.3 us between two contexts at 4096^2 x 1, -0.7 us at 4096^2 x 3.
 template <int BYTE>
 __device__ __forceinline__ unsigned byte_x16(unsigned word)
 {

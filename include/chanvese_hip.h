@@ -96,8 +96,8 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "graph"          1 = runs of 16 steps are replayed as one hipGraph (default), 0 = plain launches
  *   "kernel"         data flow of the CSV step: -1 auto (3 where it applies -- width a multiple of 16 and >= 144, from 0.6 Mpixel; three
  *                    channels in FAST arithmetic only -- else 2; 0 from 2^28 pixels),
- *                    0 LDS tile, 1 streaming strip (w % 16 == 0), 2 wave-streaming, 3 wave-streaming with
- *                    2 pixels per lane (w % 16 == 0, w >= 144; other shapes fall back to 2)
+ *                    0 LDS tile, 2 wave-streaming, 3 wave-streaming with 2 pixels per lane (w % 16 == 0, w >= 144; other shapes
+ *                    fall back to 2).  (1, the streaming-strip kernel of round 1, was removed in round 4: CVH_ERR_ARG)
  *   "resident"       -1 auto (default), 0 off, 1 on: planes whose level set fits the LDS of the chip (1 channel, FAST, even width,
  *                    at most one 128 x 128 tile per CU: up to 2048 x 2048 on an MI355X) iterate IN LDS -- one cooperative launch per
  *                    chunk of iterations, one workgroup per tile, a grid barrier per iteration, the stop rule inside the kernel at the
@@ -106,13 +106,16 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while ONE context's ping-pong
  *                    pair fits the Infinity Cache, <= 300 MB), 0 plain, 1 write-through; a caller that keeps several
  *                    contexts busy on one GPU should set 0
- *   "tile_rows"      tile/strip kernels: rows per tile (0 auto, 12/14/16)
- *   "strip_rows"     strip/wave kernels: rows per strip (0 auto)
- *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default)
+ *   "near_switch"    1 (default): a wave whose strip / band starts where most pixels are below the far-field threshold of H_eps (32 eps)
+ *                    evaluates the table form of H_eps on every pixel of that strip (one form per pixel: a level set that is near
+ *                    everywhere, e.g. dt << 1); 0: the far-field series with the per-group correction everywhere
+ *   "tile_rows"      tile kernel: rows per tile (0 auto, 14/16)
+ *   "strip_rows"     wave kernels: rows per strip (0 auto)
+ *   "lut"            1 = region term from a per-launch 256-entry table (FAST, default; tile and 1-pixel wave kernels: 0 = computed)
  *   "dma"            tile kernel: 1 = global->LDS DMA loader (slower on MI355X, default 0)
  *   "pm_kernel"      Perona-Malik data flow: -1 auto (= 4 where the plane qualifies, else 3), 0 LDS tile,
- *                    1 wave-streaming, 2 wave-streaming with 2 pixels per lane (even w >= 128),
- *                    3 wave-streaming with TWO time steps per launch (an odd last step runs flavour 1),
+ *                    1 wave-streaming, 3 wave-streaming with TWO time steps per launch (an odd last step runs flavour 1),
+ *                    (2, a 2-pixel-per-lane 1-step kernel, was removed in round 4: CVH_ERR_ARG)
  *                    4 resident plane: the FP64 state of a channel stays in the LDS of the CUs for all time steps, one
  *                    cooperative launch per channel (even width, >= 16 rows and columns, <= 128 rows x 128 columns per CU:
  *                    up to 2048 x 2048 on MI355X; CVH_ERR_ARG if asked for a plane that does not qualify; auto steps

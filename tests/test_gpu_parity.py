@@ -85,13 +85,12 @@ def test_csv_two_pixel_kernel_edge_shapes(capi, oracle, shape, mode, math):
         assert np.array_equal(m_g, oracle.mask(u_c))
 
 
-@pytest.mark.parametrize("lut", [1, 0])
 @pytest.mark.parametrize("shape", [(1, 144), (2, 160), (3, 256), (5, 2016), (9, 272), (40, 144), (17, 1008), (8, 4096), (150, 528)])
-def test_csv_three_channel_two_pixel_kernel(capi, oracle, shape, lut):
+def test_csv_three_channel_two_pixel_kernel(capi, oracle, shape):
     """Round 3: the 2-pixel wave kernel with three channels (csv_wave2_kernel<3, ...>, FAST only, "kernel" = 3): one image
-    tile per channel, samples read inside the row, region term from three tables (lut = 1) or as the quadratic
-    sum_k (qa_k I + qb_k) I + qc with wave-uniform coefficients (lut = 0).  Same shapes as the 1-channel edge-shape test,
-    per-channel lambdas, nu != 0, ragged strips."""
+    tile per channel, samples read inside the row, region term from three tables (the table-free quadratic form of round 3 was
+    pruned in round 4: tools/experiments/pruned_flavours/).  Same shapes as the 1-channel edge-shape test, per-channel lambdas,
+    nu != 0, ragged strips."""
     h, w = shape
     rng = np.random.default_rng(7 * h + w)
     planes = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]
@@ -101,11 +100,9 @@ def test_csv_three_channel_two_pixel_kernel(capi, oracle, shape, lut):
         u_c, _, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
         with capi.Context(h, w, 3, capi.make_params(**pk)) as ctx:
             ctx.set_option("kernel", 3)
-            ctx.set_option("lut", lut)
             for k, v in opts.items():
                 ctx.set_option(k, v)
             assert ctx.launch_info()["kernel"].startswith("csv_wave2_kernel<3, true, 3, "), ctx.launch_info()
-            assert ctx.launch_info()["kernel"].endswith("true>" if lut == 0 else "false>")
             ctx.set_option("trace", steps)
             ctx.set_image(planes)
             ctx.set_levelset(u0)
@@ -125,7 +122,7 @@ def test_launch_info_names_what_runs(capi):
         assert ctx.launch_info()["kernel"] == "csv_resident_kernel<4>"       # the default for a plane that fits the chip's LDS: 32 x 8 tiles of 32 rows, 4 per wave
         ctx.set_option("resident", 0)
         i = ctx.launch_info()
-        assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1, false>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"
+        assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"
         ctx.set_option("kernel", 2)
         assert ctx.launch_info()["kernel"].startswith("csv_wave_kernel<1, true, true, 5, true, 1, 1>")
         ctx.set_option("math_mode", 1)
@@ -146,14 +143,10 @@ def test_launch_info_names_what_runs(capi):
 @pytest.mark.parametrize("mode,math", MODES)
 @pytest.mark.parametrize("opts", [dict(kernel=0, tile_rows=14), dict(kernel=0, tile_rows=16, lut=0),
                                   dict(kernel=0, tile_rows=14, dma=1),
-                                  dict(kernel=1, tile_rows=16, strip_rows=16),
-                                  dict(kernel=1, tile_rows=16, strip_rows=48),
-                                  dict(kernel=1, tile_rows=12, strip_rows=24, lut=0),
-                                  dict(kernel=1, tile_rows=12), dict(kernel=1, tile_rows=16),
                                   dict(kernel=2), dict(kernel=2, strip_rows=8, lut=0),
                                   dict(kernel=2, strip_rows=52, wave_occupancy=4),
                                   dict(kernel=2, strip_rows=1000, wave_skew=150, wave_prio=2),
-                                  dict(kernel=3), dict(kernel=3, strip_rows=8), dict(kernel=3, strip_rows=37, wave_occupancy=4),
+                                  dict(kernel=3), dict(kernel=3, strip_rows=8), dict(kernel=3, strip_rows=37),
                                   dict(kernel=3, strip_rows=1000, wave_xcd=0)])
 def test_csv_kernel_variants(capi, oracle, mode, math, opts):
     """Every data-flow variant of the step kernel (LDS tile / streaming strip, ring chunking,
@@ -451,8 +444,7 @@ def test_enqueue_sync_interleaved_contexts(capi, oracle):
         c.close()
 
 
-@pytest.mark.parametrize("pm_opts", [dict(pm_kernel=2), dict(pm_kernel=2, pm_strip_rows=8), dict(pm_kernel=2, pm_strip_rows=20),
-                                     dict(pm_kernel=1), dict(pm_kernel=1, pm_strip_rows=8), dict(pm_kernel=0), dict(),
+@pytest.mark.parametrize("pm_opts", [dict(pm_kernel=1), dict(pm_kernel=1, pm_strip_rows=8), dict(pm_kernel=0), dict(),
                                      dict(pm_kernel=3), dict(pm_kernel=3, pm_strip_rows=8), dict(pm_kernel=3, pm_strip_rows=24),
                                      dict(pm_strip_rows=16)])
 @pytest.mark.parametrize("shape,K,L,T", [((40, 56), 30, 0.25, 5), ((64, 64), 10, 0.25, 20),
@@ -460,8 +452,7 @@ def test_enqueue_sync_interleaved_contexts(capi, oracle):
                                          ((50, 1), 30, 0.25, 2), ((3, 3), 30, 0.2, 1),
                                          ((1, 128), 10, 0.25, 2), ((9, 248), 20, 0.25, 3), ((70, 372), 30, 0.25, 4)])
 def test_perona_malik_parity(capi, oracle, shape, K, L, T, pm_opts):
-    """Every Perona-Malik data flow (tile, wave, wave with 2 pixels per lane: even widths >= 128, one or several
-    wave-columns of 124, exact and partial; wave with TWO time steps per launch: even and odd trip counts, strips
+    """Every Perona-Malik data flow (tile, wave; wave with TWO time steps per launch: even and odd trip counts, strips
     shorter than / equal to / longer than the image; no option: the resident-plane kernel where the shape qualifies --
     tests/test_gpu_pm_resident.py -- and the 2-step kernel elsewhere) against the oracle."""
     h, w = shape

@@ -34,12 +34,12 @@ def test_no_valu_write_in_the_issue_slot_behind_a_wide_store(report):
 
 def test_every_streaming_kernel_with_wide_stores_was_seen(report):
     """The check is only worth something if it saw the kernels it is about: the 2-pixel CSV kernels (16-byte level-set
-    stores: >= 8 per instantiation, one per row of the two loop bodies) and the 2-pixel Perona-Malik kernel."""
+    stores: >= 8 per instantiation, one per row of the loop bodies)."""
     names = {k["kernel"]: k for k in report["kernels"]}
     wave2 = [k for n, k in names.items() if "csv_wave2_kernel" in n]
-    assert len(wave2) >= 7, sorted(names)            # 1-channel: strict, 4 waves/SIMD, three cache policies; 3-channel: 2 x 2
+    assert len(wave2) >= 6, sorted(names)            # 1-channel: strict, three cache policies; 3-channel: two cache policies
     for k in wave2:
         assert k["wide_stores"] >= 8, k
         assert k["register_soffset_stores"] >= 8, k                  # the form hipcc does not pad
         assert k["min_wait_states_register_soffset"].get("valu", 1 << 30) >= 6, k     # by construction: live to the end of the group
-    assert any("pm_wave2_kernel" in n for n in names)
+    # (the 2-pixel Perona-Malik kernel, the other kernel with 16-byte stores, was pruned in round 4: tools/experiments/pruned_flavours/)

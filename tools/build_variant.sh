@@ -8,7 +8,7 @@ name=$1; shift
 mkdir -p variants/$name
 FILE=${FILE:-csv_wave2_kernel}
 objs=""
-for f in api csv_kernels csv_strip_kernel csv_wave_kernel csv_wave2_kernel csv_resident_kernel pm_kernels pm_wave2_kernel pm_wave_k2_kernel pm_resident_kernel chain_kernels misc_kernels; do
+for f in api csv_kernels csv_wave_kernel csv_wave2_kernel csv_resident_kernel pm_kernels pm_wave_k2_kernel pm_resident_kernel chain_kernels misc_kernels; do
   [ $f = $FILE ] || objs="$objs $f.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-function "$@" -c $FILE.hip -o variants/$name/$FILE.o
