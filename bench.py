@@ -81,8 +81,12 @@ CONFIGS = {
     # the regime of the reference README's second example (README.md:58-63, --dt 0.001): the level set stays below the far-field
     # threshold of H_eps (32 eps) everywhere for the whole run, so every pixel takes the table form of H_eps in every iteration
     "near":     (4096, 1, 1, 500, "clean disk, dt = 0.001: every pixel stays in the near field of H_eps (|u| < 32 eps) for the whole run"),
+    # DECLARED FP32-state mode (option "state" = 32; SURVEY.md 8d: 9 / 11 algorithmic bytes per pixel-iteration): never the default
+    "C2-f32":   (4096, 1, 1, 500, "clean disk (BASELINE configs[1]) with the level set stored as FLOAT in HBM (declared mode: FP64 arithmetic and sums, every new value rounded to float)"),
+    "C3-f32":   (4096, 3, 1, 300, "3-channel disks, lambda1 1 1 0.5, lambda2 1 0.5 1 (BASELINE configs[2]) with the level set stored as FLOAT in HBM (declared mode)"),
 }
 CONFIG_DT = {"near": 0.001}
+CONFIG_STATE = {"C2-f32": 32, "C3-f32": 32}
 
 
 def parse(argv=None):
@@ -152,7 +156,7 @@ def expected_disk(name, n, gb):
     ii = np.arange(n, dtype=np.int64)[:, None] - n // 2
     jj = np.arange(n, dtype=np.int64)[None, :] - n // 2
     disk = ii * ii + jj * jj <= r * r
-    levels = [(180, 40), (200, 60), (60, 200)] if name == "C3" else [(200, 50)]
+    levels = [(180, 40), (200, 60), (60, 200)] if name in ("C3", "C3-f32") else [(200, 50)]
     noise = {"C4": 32, "C4-image": 32, "C5": 16, "C5-image": 16}.get(name, 0)
     return disk, levels, noise
 
@@ -198,7 +202,7 @@ def verify_result(name, n, gb, ctx, iterations):
 
 def image_planes(name, n, gb):
     from chan_vese_amd import synth
-    if name == "C3":
+    if name in ("C3", "C3-f32"):
         return synth.config_planes("C3", n)
     if name in ("C4", "C4-image"):
         return synth.config_planes("C4", n)
@@ -225,6 +229,7 @@ def main():
 
     name, n, C, images, steps, desc = resolve_workload(args, world)
     math_mode = {"strict": 1, "fast": 2}[args.math]
+    state_bits = CONFIG_STATE.get(name, 64)
     pm_info = None
     phases = None
     ctxs = []
@@ -241,6 +246,7 @@ def main():
             ctx = capi.Context(n, n, C, p, device=device)
             ctx.set_option("math_mode", math_mode)
             ctx.set_option("finalize", args.finalize)
+            ctx.set_option("state", state_bits)
             if images > 1 and C == 1:
                 # several images share the GPU: their level sets (8 x 272 MiB) do not live in the Infinity Cache, where write-through
                 # stores cost (cache policy; measured 292.6-293.5 k vs 288.3-289.3 k Mpx-it/s)
@@ -306,6 +312,7 @@ def main():
         if scratch is None:
             scratch = capi.Context(n, n, C, capi.make_params(tol=0.0, dt=CONFIG_DT.get(name, 1.0)), device=device)
             scratch.set_option("math_mode", math_mode)
+            scratch.set_option("state", state_bits)
             for kv in args.opt:
                 k, v = kv.split("=")
                 scratch.set_option(k, int(v))
@@ -360,7 +367,7 @@ def main():
 
     out = None
     if rank == 0:
-        bytes_per_launch = (2 * 8 + C) * float(n) * n      # read u, write u, read C planes
+        bytes_per_launch = (2 * (state_bits // 8) + C) * float(n) * n      # read u, write u, read C planes (FP32 state: 9 / 11 B)
         avg_launch_s = max((sum(kernel_ms) / len(kernel_ms)) / 1e3 / max(steps, 1), 1e-12)
         if images > 1:
             avg_launch_s /= images                         # streams overlap: per-launch share of the span
@@ -404,10 +411,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if state_bits == 64 else "f32",
             "data": "synthetic" if not dry else "dry-run",
             "config": {"workload": workload, "images_per_gpu": images, "images_total": images * world,
-                       "state": "fp64", "math": args.math,
+                       "state": "fp64" if state_bits == 64 else "fp32 in HBM (DECLARED mode: every new level-set value rounded to float; arithmetic, tables and sums FP64 / 64-bit fixed point)",
+                       "math": args.math,
                        "device_prewarm": f"{prewarm_launches} launches on a scratch context between the warm-up steps and the timed steps", "parallelism": f"batch-shard x{world}",
                        "ranks_in_group": (dist.get_world_size() if dist is not None else 1),
                        "backend": (dist.get_backend() if dist is not None else "none"),

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "cvh_internal.h"
@@ -24,6 +26,16 @@ struct cvh_context {
   size_t img_stride = 0;
   double *d_u[2] = {nullptr, nullptr};
   void *d_u_slab = nullptr;
+  // option "state" = 32 (declared FP32-state mode): the iteration kernels read and write d_uf[]; d_u[] stays the exchange format of
+  // set / get / mask / contour / selection and of the initial sums -- a mirror, refreshed lazily (ensure_f64_mirror)
+  int state_bits = 64;
+  float *d_uf[2] = {nullptr, nullptr};
+  void *d_uf_slab = nullptr;
+  bool mirror_valid = true;     // d_u[current] holds the level set (always true with 64-bit state)
+  // automatic cache policy of a run ("wave_pol" = -1): decided when the run's first iteration is enqueued, from the footprint of EVERY
+  // context on this device that holds an image and a level set (live_footprint), and kept until the run counter is reset
+  int co_resident = 1;          // option "co_resident": 0 = a scratch / warm-up context that does not stream beside the others
+  mutable int run_pol = -1;     // the decision of the current run (-1: not taken yet)
   CvhState *d_state = nullptr;
   CvhState *h_state = nullptr;  // pinned, four slots for pipelined polling
   double *d_partials = nullptr;
@@ -163,13 +175,37 @@ static int check_params(cvh_context *ctx, const cvh_params *p, int C)
   return CVH_OK;
 }
 
+// Every live context of the process (cvh_create .. cvh_destroy).  Several contexts on one GPU share its 256 MiB Infinity Cache: what one
+// context's footprint suggests (write-through stores while its ping-pong pair fits the cache) is wrong when eight of them stream side by
+// side -- the batch BASELINE configs[4] describes.  Round 3 left that to the caller ("wave_pol" = 0); now the automatic choice looks here.
+static std::mutex g_live_mu;
+static std::vector<cvh_context *> g_live;
+static double live_footprint(const cvh_context *c);
+
+// bytes per pixel-iteration pair (level-set ping-pong + planes) of every context on c's device that holds an image and a level set and
+// streams beside the others ("co_resident")
+static double live_footprint(const cvh_context *c)
+{
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  double sum = 0.0;
+  for (const cvh_context *o : g_live)
+    if (o->device == c->device && o->co_resident && ((o->have_u && o->have_image) || o == c))
+      sum += (double)o->n * (2.0 * (o->state_bits / 8) + o->C);
+  return sum;
+}
+
 extern "C" void cvh_destroy(cvh_context *c)
 {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->d_img_slab) (void)hipFree(c->d_img_slab);
   if (c->d_u_slab) (void)hipFree(c->d_u_slab);
+  if (c->d_uf_slab) (void)hipFree(c->d_uf_slab);
   for (int k = 0; k < 2; ++k) if (c->d_pm[k]) (void)hipFree(c->d_pm[k]);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->h_state) (void)hipHostFree(c->h_state);
@@ -283,6 +319,10 @@ extern "C" int cvh_create(cvh_context **out, int h, int w, int channels, const c
     cvh_destroy(c);
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.push_back(c);
+  }
   *out = c;
   return CVH_OK;
 }
@@ -298,6 +338,9 @@ extern "C" int cvh_set_params(cvh_context *c, const cvh_params *p)
 }
 
 static int sync_impl(cvh_context *c);
+
+static int ensure_f64_mirror(cvh_context *c);
+static int adopt_f32_state(cvh_context *c);
 
 extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
 {
@@ -373,6 +416,27 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     c->wave_sync = value < 0 ? -1 : (value != 0);
   } else if (!strcmp(key, "near_switch")) {
     c->near_switch = value != 0;
+  } else if (!strcmp(key, "co_resident")) {
+    c->co_resident = value != 0;
+  } else if (!strcmp(key, "state")) {
+    // 64 (default): the level set lives in HBM as double, the reference's CV_64FC1 (src/main.cpp:225) -- the parity mode.
+    // 32: DECLARED fast mode -- float in HBM (9 instead of 17 bytes per pixel-iteration), arithmetic and sums unchanged; every new value is
+    // rounded to float.  2-pixel wave kernel only (FAST arithmetic, width a multiple of 16 and >= 144, < 2^28 pixels).
+    if (value != 32 && value != 64) return fail(c, CVH_ERR_ARG, "state must be 64 or 32");
+    if ((int)value != c->state_bits) {
+      if (value == 32) {
+        if (c->w % 16 != 0 || c->w < 144 || c->n >= ((size_t)1 << 28))
+          return fail(c, CVH_ERR_ARG, "state 32 needs a width that is a multiple of 16 and >= 144, and fewer than 2^28 pixels (the 2-pixel wave kernel)");
+        if (c->have_u) { const int rc = ensure_f64_mirror(c); if (rc != CVH_OK) return rc; }
+        c->state_bits = 32;
+        if (c->have_u) { const int rc = adopt_f32_state(c); if (rc != CVH_OK) return rc; }
+      } else {
+        if (c->have_u) { const int rc = ensure_f64_mirror(c); if (rc != CVH_OK) return rc; }
+        c->state_bits = 64;
+        c->mirror_valid = true;
+      }
+      c->sums_valid = false;
+    }
   } else if (!strcmp(key, "wave_prio")) {
     if (value < 0 || value > 4) return fail(c, CVH_ERR_ARG, "wave_prio must be 0..4");
     c->wave_prio = (int)value;
@@ -487,6 +551,36 @@ extern "C" int cvh_get_image(cvh_context *c, uint8_t *const *planes)
 
 static int current_buffer(const cvh_context *c) { return (c->cur_base + c->steps_done) & 1; }
 
+// FP32 state: the float buffers (lazily allocated) take over the level set that d_u[current] holds -- rounded to float, and d_u[current]
+// is rewritten with the rounded values, so that whatever reads the mirror (initial sums, mask, get) sees what the kernels iterate on.
+static int adopt_f32_state(cvh_context *c)
+{
+  if (!c->d_uf_slab) {
+    const size_t each = (((c->n + 64) * sizeof(float)) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    HIPCHK(c, hipMalloc((void **)&c->d_uf_slab, 2 * each));
+    c->d_uf[0] = (float *)c->d_uf_slab;
+    c->d_uf[1] = (float *)((char *)c->d_uf_slab + each);
+  }
+  const int cur = current_buffer(c);
+  HIPCHK(c, cvh_launch_state_narrow(c->d_u[cur], c->d_uf[cur], c->n, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->mirror_valid = true;
+  c->sums_valid = false;
+  return CVH_OK;
+}
+
+// FP32 state: d_u[current] = (double) d_uf[current] if launches have run since the mirror was last refreshed (call behind a sync).
+static int ensure_f64_mirror(cvh_context *c)
+{
+  if (c->state_bits != 32 || c->mirror_valid) return CVH_OK;
+  if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
+  const int cur = current_buffer(c);
+  HIPCHK(c, cvh_launch_state_widen(c->d_uf[cur], c->d_u[cur], c->n, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->mirror_valid = true;
+  return CVH_OK;
+}
+
 static int reset_run_impl(cvh_context *c)
 {
   if (c->timing_open || c->chain_pending) { const int rc = sync_impl(c); if (rc != CVH_OK) return rc; }
@@ -524,6 +618,8 @@ extern "C" int cvh_set_levelset(cvh_context *c, const double *u)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_u = true;
   c->sums_valid = false;
+  c->mirror_valid = true;
+  if (c->state_bits == 32) { const int rc = adopt_f32_state(c); if (rc != CVH_OK) return rc; }
   return reset_run_impl(c);
 }
 
@@ -560,6 +656,8 @@ extern "C" int cvh_init_checkerboard(cvh_context *c)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_u = true;
   c->sums_valid = false;
+  c->mirror_valid = true;
+  if (c->state_bits == 32) { const int rc = adopt_f32_state(c); if (rc != CVH_OK) return rc; }
   return reset_run_impl(c);
 }
 
@@ -568,6 +666,7 @@ extern "C" int cvh_get_levelset(cvh_context *c, double *u)
   if (!c || !u) return CVH_ERR_ARG;
   if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_get_levelset: no level set");
   HIPCHK(c, hipSetDevice(c->device));
+  { const int rc = ensure_f64_mirror(c); if (rc != CVH_OK) return rc; }
   HIPCHK(c, hipMemcpyAsync(u, c->d_u[current_buffer(c)], c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return CVH_OK;
@@ -588,9 +687,9 @@ static Geometry resolve_geometry(const cvh_context *c)
   // 140.7, 4320x7680 122.7 vs 123.2, 8192^2 243.3 vs 245.5)
   // three channels: the 2-pixel flavour exists in FAST arithmetic only; with equal strips (no class skew) it is the faster one from
   // round 3 on (4096^2 x 3, one context, alternating: 73.3 vs 74.9 us; bench lines of one session: 72.9 / 74.3 vs 74.5 / 76.1 us)
-  const bool two_px_c3 = c->C == 3 && use_fast(c) && (c->kernel == 3 || c->kernel == -1);
-  if ((c->kernel == 3 || (c->kernel == -1 && c->n >= (size_t)600000)) && (c->C == 1 || two_px_c3) && c->w % 16 == 0 && c->w >= 144 &&
-      c->n < ((size_t)1 << 28)) {
+  const bool two_px_c3 = c->C == 3 && use_fast(c) && (c->kernel == 3 || c->kernel == -1 || c->state_bits == 32);
+  if ((c->kernel == 3 || c->state_bits == 32 || (c->kernel == -1 && c->n >= (size_t)600000)) && (c->C == 1 || two_px_c3) && c->w % 16 == 0 &&
+      c->w >= 144 && c->n < ((size_t)1 << 28)) {
     // wave kernel with 2 pixels per lane: 126 output columns per wave; workgroup = 2 wave-columns x 2 strips;
     // one round of resident waves (3 or 4 per SIMD)
     g.strip = 3;
@@ -681,6 +780,7 @@ static bool resident_tiles(const cvh_context *c, int cap_blocks, ResidentGeom *r
 static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
 {
   if (!c->resident_opt || c->C != 1 || !use_fast(c) || !c->chain_opt || c->finalize_mode != 0 || (c->w & 1) || c->w < 16 || c->h < 16) return false;
+  if (c->state_bits == 32) return false;      // the FP32-state mode is the 2-pixel per-launch kernel's
   if (!(c->kernel == -1 || c->kernel == 2 || c->kernel == 3)) return false;
   // auto: a caller who chose a per-launch data flow or tuned its geometry / launch path gets that flow (measured, one context per size,
   // resident vs per-launch: 128^2 7.4 vs 7.6 us, 256^2 6.9 vs 7.6, 768^2 8.5 vs 9.8, 1024x2048 11.5 vs 14.6, 1536^2 12.4 vs 16.2,
@@ -729,6 +829,12 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   memset(a, 0, sizeof(*a));
   a->u_in = c->d_u[in_buf];
   a->u_out = c->d_u[in_buf ^ 1];
+  a->state32 = 0;
+  if (c->state_bits == 32) {   // FP32 state: the step kernel's pair are the float buffers (prepare() points the initial sums at the mirror)
+    a->u_in = reinterpret_cast<const double *>(c->d_uf[in_buf]);
+    a->u_out = reinterpret_cast<double *>(c->d_uf[in_buf ^ 1]);
+    a->state32 = 1;
+  }
   for (int k = 0; k < c->C; ++k) a->img[k] = c->d_img[k];
   a->img_stride = (unsigned)c->img_stride;
   a->st = c->d_state;
@@ -782,7 +888,11 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   // on request ("wave_cls" = 2): measured neutral to slightly worse there (4096^2 x 3 channels: 77.2 plain, 77.3 class-major, 82.5 with
   // skew 500; 1 channel: 63.6 / 64.3)
   // write-through stores pay while the ping-pong pair and the planes (mostly) fit the 256 MiB Infinity Cache: up to ~300 MB of footprint
-  a->wave_pol = c->wave_pol >= 0 ? c->wave_pol : ((double)c->n * (16.0 + c->C) <= 300e6 ? 1 : 0);
+  if (c->wave_pol >= 0) a->wave_pol = c->wave_pol;
+  else {   // auto, per run: taken (and re-taken, while nothing of the run is enqueued) from the device's live footprint, then kept
+    if (c->run_pol < 0 || c->enqueued == 0) c->run_pol = live_footprint(c) <= 300e6 ? 1 : 0;
+    a->wave_pol = c->run_pol;
+  }
   a->wave_cls = (((g.strip == 3 && c->wave_cls) || (g.strip == 2 && c->wave_cls == 2)) && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
   a->host_status = c->h_status;
   a->dbg_times = c->d_dbg;
@@ -817,6 +927,8 @@ static int prepare_host(cvh_context *c)
     if (rc != CVH_OK) return rc;
   }
   c->stop_cond_h = c->p.tol * c->stop_norm;  // :959 (a launch argument: part of the graph key)
+  if (c->state_bits == 32 && (!use_fast(c) || resolve_geometry(c).strip != 3))
+    return fail(c, CVH_ERR_ARG, "state 32 runs the 2-pixel wave kernel in FAST arithmetic only (math_mode, kernel)");
   return CVH_OK;
 }
 
@@ -831,6 +943,11 @@ static int prepare(cvh_context *c)
   if (!c->sums_valid) {
     CvhStepArgs a;
     fill_args(c, &a, current_buffer(c), c->enqueued);
+    if (c->state_bits == 32) {   // the sums of the level set the run starts from are taken of its double mirror (the rounded values)
+      const int rc = ensure_f64_mirror(c);
+      if (rc != CVH_OK) return rc;
+      a.u_in = c->d_u[current_buffer(c)];
+    }
     int nparts = 0;
     HIPCHK(c, cvh_launch_init_sums(a, c->C, use_fast(c), &nparts, c->stream));
     a.nparts = nparts;
@@ -1060,6 +1177,7 @@ static int launch_resident(cvh_context *c, const ResidentGeom &rg, int nsteps, C
 
 static int enqueue_impl(cvh_context *c, int nsteps)
 {
+  if (c->state_bits == 32 && nsteps > 0) c->mirror_valid = false;
   {
     ResidentGeom rg;
     if (resident_geometry(c, &rg)) return launch_resident(c, rg, nsteps, nullptr);
@@ -1255,6 +1373,7 @@ extern "C" int cvh_get_mask(cvh_context *c, uint8_t *mask, int invert)
   if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_get_mask: no level set");
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->d_mask) HIPCHK(c, hipMalloc((void **)&c->d_mask, c->n));
+  { const int rc = ensure_f64_mirror(c); if (rc != CVH_OK) return rc; }
   HIPCHK(c, cvh_launch_mask(c->d_u[current_buffer(c)], c->d_mask, c->n, invert, c->stream));
   HIPCHK(c, hipMemcpyAsync(mask, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1267,6 +1386,7 @@ extern "C" int cvh_get_contour(cvh_context *c, uint8_t *contour)
   if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_get_contour: no level set");
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->d_mask) HIPCHK(c, hipMalloc((void **)&c->d_mask, c->n));
+  { const int rc = ensure_f64_mirror(c); if (rc != CVH_OK) return rc; }
   HIPCHK(c, cvh_launch_contour(c->d_u[current_buffer(c)], c->d_mask, c->h, c->w, c->stream));
   HIPCHK(c, hipMemcpyAsync(contour, c->d_mask, c->n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1278,6 +1398,7 @@ extern "C" int cvh_separate(cvh_context *c, const uint8_t *img3, int invert, uin
   if (!c || !img3 || !selection3) return CVH_ERR_ARG;
   if (!c->have_u) return fail(c, CVH_ERR_STATE, "cvh_separate: no level set");
   HIPCHK(c, hipSetDevice(c->device));
+  { const int rc = ensure_f64_mirror(c); if (rc != CVH_OK) return rc; }
   uint8_t *d_in = nullptr, *d_out = nullptr;
   HIPCHK(c, hipMalloc((void **)&d_in, c->n * 3));
   hipError_t e = hipMalloc((void **)&d_out, c->n * 3);

@@ -27,10 +27,12 @@ using namespace cvh_dev;
 
 namespace {
 
-template <int C, bool FAST, int MINW, int POL>
+template <int C, bool FAST, int MINW, int POL, bool ST32>
 __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhStepArgs a)
 {
   static_assert(C == 1 || FAST, "the 3-channel flavour exists in FAST arithmetic only (STRICT: kernel 2)");
+  static_assert(!ST32 || FAST, "the declared FP32-state mode exists in FAST arithmetic only");
+  using IO = StateIO<ST32, POL>;             // the level set's format in HBM (wave2_device.h): FP64, or the declared FP32 state
   static_assert(FAST ? MINW == 3 : MINW == 2, "compiled for 3 waves per SIMD (FAST: branch-free rows) or 2 (STRICT)");
   using L = Wave2Smem<FAST, C>;
   constexpr int NS = cvh_nsums(C), R = R2;
@@ -162,16 +164,19 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     const int xrow = xlane ? lane : 0;
     const int xcol = clampi(W2 * wc + W2, 0, w - 1);
     double *x_ext = xlane ? xs + xrow * XP2 + 128 : xs + R * XP2 + lane;   // other lanes: scratch
-    const unsigned rowbytes = (unsigned)w * 8u, ubytes = (unsigned)h * rowbytes;
-    const unsigned voff_u = (unsigned)cl * 8u;
-    const unsigned voff_st = lane_valid ? (unsigned)c0 * 8u : kOobOffset;
-    const unsigned voff_x = ((unsigned)xrow * (unsigned)w + (unsigned)xcol) * 8u;
+    using raw2_t = typename IO::raw2_t;
+    using raw1_t = typename IO::raw1_t;
+    constexpr unsigned SB = IO::kBytes;                          // bytes of a level-set value in HBM
+    const unsigned rowbytes = (unsigned)w * SB, ubytes = (unsigned)h * rowbytes;
+    const unsigned voff_u = (unsigned)cl * SB;
+    const unsigned voff_st = lane_valid ? (unsigned)c0 * SB : kOobOffset;
+    const unsigned voff_x = ((unsigned)xrow * (unsigned)w + (unsigned)xcol) * SB;
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u_in, ubytes);
     const int ulast = s1 < h - 1 ? s1 : h - 1, ilast = s1 - 1;
-    auto U = [&](int r) -> double2_t { return buf_load_f64x2<POL>(ru, voff_u, (unsigned)clampi(r, 0, ulast) * rowbytes); };
-    auto UX = [&](int r0) -> double {
-      if (r0 + R - 1 <= ulast) return buf_load_f64(ru, voff_x, (unsigned)r0 * rowbytes);
-      return buf_load_f64(ru, ((unsigned)clampi(r0 + xrow, 0, ulast) * (unsigned)w + (unsigned)xcol) * 8u, 0u);
+    auto U = [&](int r) -> raw2_t { return IO::load2(ru, voff_u, (unsigned)clampi(r, 0, ulast) * rowbytes); };
+    auto UX = [&](int r0) -> raw1_t {
+      if (r0 + R - 1 <= ulast) return IO::load1(ru, voff_x, (unsigned)r0 * rowbytes);
+      return IO::load1(ru, ((unsigned)clampi(r0 + xrow, 0, ulast) * (unsigned)w + (unsigned)xcol) * SB, 0u);
     };
     // image: 9 aligned 16-byte pieces per row, R rows by 9R lanes, staged in the per-wave tile
     unsigned char *simg = reinterpret_cast<unsigned char *>(xs + R * XP2 + 64);
@@ -215,11 +220,11 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     int im[R];   // the group's samples: byte of a | byte of b << 8   (C = 1; three channels read them inside the row)
-    auto park = [&](const double2_t (&T)[R], double X, const u32x4_t (&IQ)[NIQ]) {
+    auto park = [&](const raw2_t (&T)[R], raw1_t X, const u32x4_t (&IQ)[NIQ]) {   // (the ring holds doubles whatever the format in HBM)
       lds_fence();
 #pragma unroll
-      for (int j = 0; j < R; ++j) x_put[j * (XP2 / 2)] = T[j];
-      *x_ext = X;
+      for (int j = 0; j < R; ++j) x_put[j * (XP2 / 2)] = IO::widen(T[j]);
+      *x_ext = IO::widen(X);
       if (C == 1) {
         if (ilane) *reinterpret_cast<u32x4_t *>(ipiece_dst) = IQ[0];
       } else {
@@ -236,15 +241,15 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
     auto samples = [&](int ch, int k) -> int { return (int)*reinterpret_cast<const unsigned short *>(simg + (ch * R + k) * IMGP2 + ibyte); };
 
     // ---- prologue
-    const double2_t um2 = U(s0 - 2);
-    double2_t um = U(s0 - 1), u0 = U(s0);
+    const double2_t um2 = IO::widen(U(s0 - 2));
+    double2_t um = IO::widen(U(s0 - 1)), u0 = IO::widen(U(s0));
     double uw, ue;
     {
-      double2_t T[R];
+      raw2_t T[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) T[j] = U(s0 + 1 + j);
-      const double X0 = UX(s0);
-      const double X = UX(s0 + 1);
+      const double X0 = IO::widen(UX(s0));
+      const raw1_t X = UX(s0 + 1);
       u32x4_t IQ[NIQ];
       if (C == 1) IQ[0] = IMQ(s0);
       else {
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       // the registers are harmless.  The stored pair lives in keep[k] until the END of the group (the branch-free flavour needs
       // it there anyway, the others pin it below), so nothing writes it for hundreds of instructions, and
       // tools/isa_store_hazard.py checks the emitted ISA of every instantiation (tests/test_isa_hazard.py).
+      if (ST32) { va = IO::stored(va); vb = IO::stored(vb); }   // FP32 state: what the next iteration will load is what H_eps is taken of
       keep[k] = double2_t{va, vb};
       if (FAST && DEFER && NEARFORM) {   // H_eps of the whole group is taken behind its rows, in the table form (group())
         hva = 0.0; hvb = 0.0;
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
       } else {
         hva = heaviside_strict(va, eps); hvb = heaviside_strict(vb, eps);
       }
-      buf_store_f64x2<POL>(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
+      IO::store2(keep[k], make_rsrc(a.u_out, live ? ubytes : 0u), voff_st, (unsigned)i * rowbytes);
       if (live) {
         if (FAST && DEFER && NEARFORM) {   // the sums of H follow behind the rows
           acc[2 + 2 * C] = __builtin_fma(uda, uda, acc[2 + 2 * C]); acc[2 + 2 * C] = __builtin_fma(udb, udb, acc[2 + 2 * C]);
@@ -430,10 +436,10 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
           else __builtin_amdgcn_s_setprio(0);
         }
       }
-      double2_t T[R];
+      raw2_t T[R];
 #pragma unroll
-      for (int j = 0; j < R; ++j) T[j] = INTERIOR ? buf_load_f64x2<POL>(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
-      const double X = INTERIOR ? buf_load_f64(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
+      for (int j = 0; j < R; ++j) T[j] = INTERIOR ? IO::load2(ru, voff_u, (unsigned)(ib + R + 1 + j) * rowbytes) : U(ib + R + 1 + j);
+      const raw1_t X = INTERIOR ? IO::load1(ru, voff_x, (unsigned)(ib + R + 1) * rowbytes) : UX(ib + R + 1);
       u32x4_t IQ[NIQ];
       if (C == 1) IQ[0] = INTERIOR ? buf_load_b128(ri, voff_i, (unsigned)(ib + R) * (unsigned)w) : IMQ(ib + R);
       else {
@@ -544,13 +550,14 @@ __global__ __launch_bounds__(CVH_BLOCK, MINW) void csv_wave2_kernel(const CvhSte
   if (a.dbg_times && tid == 0) a.dbg_times[(size_t)a.nparts * 16 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int C, bool FAST, int MINW, int POL>
+template <int C, bool FAST, int MINW, int POL, bool ST32 = false>
 hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 {
   using L = Wave2Smem<FAST, C>;
   static_assert(L::bytes <= 64 * 1024, "dynamic LDS above 64 KiB would need hipFuncSetAttribute");
   const int extra = (FAST && a.chain) ? 1 : 0;   // the bookkeeping workgroup
-  CVH_LAUNCH((csv_wave2_kernel<C, FAST, MINW, POL>), a.nparts + extra, L::bytes, s, a, "csv_wave2_kernel<%d, %s, %d, %d>", C, CVH_TF(FAST), MINW, POL);
+  CVH_LAUNCH((csv_wave2_kernel<C, FAST, MINW, POL, ST32>), a.nparts + extra, L::bytes, s, a, "csv_wave2_kernel<%d, %s, %d, %d, %s>", C, CVH_TF(FAST), MINW,
+             POL, CVH_TF(ST32));
   return hipGetLastError();
 }
 
@@ -558,12 +565,17 @@ hipError_t launch_wave2(const CvhStepArgs &a, hipStream_t s)
 
 int cvh_wave2_cols() { return W2; }
 
-// Instantiations: <1, false, 2, 1> STRICT; <1, true, 3, POL> and <3, true, 3, POL> FAST with the cache policy of the rows as a template
-// parameter (wave2_device.h: 1 write-through stores + sc0 loads, 0 plain, 2 plain stores + non-temporal loads -- diagnostic).  Round 3
-// also shipped a 4-waves/SIMD flavour (95.7 against 57.3 us at 4096^2) and a table-free 3-channel region term (81 against 72 us): neither
-// was ever chosen, neither is a fallback -- tools/experiments/pruned_flavours/README.md.
+// Instantiations <channels, FAST, waves per SIMD, cache policy of the rows, FP32 state>: <1, false, 2, 1, false> STRICT; <1 | 3, true, 3,
+// POL, false> FAST (wave2_device.h: POL 1 write-through stores + sc0 loads, 0 plain, 2 plain stores + non-temporal loads -- diagnostic);
+// <1 | 3, true, 3, POL, true> the DECLARED FP32-state mode (option "state" = 32).  Round 3 also shipped a 4-waves/SIMD flavour (95.7
+// against 57.3 us at 4096^2) and a table-free 3-channel region term (81 against 72 us): neither was ever chosen, neither is a fallback --
+// tools/experiments/pruned_flavours/README.md.
 hipError_t cvh_launch_wave2(const CvhStepArgs &a, int channels, int fast, hipStream_t s)
 {
+  if (a.state32) {   // FAST only (api.hip refuses the combination with STRICT)
+    if (channels == 3) return a.wave_pol ? launch_wave2<3, true, 3, 1, true>(a, s) : launch_wave2<3, true, 3, 0, true>(a, s);
+    return a.wave_pol ? launch_wave2<1, true, 3, 1, true>(a, s) : launch_wave2<1, true, 3, 0, true>(a, s);
+  }
   if (channels == 3) return a.wave_pol ? launch_wave2<3, true, 3, 1>(a, s) : launch_wave2<3, true, 3, 0>(a, s);   // FAST only (api.hip routes STRICT to kernel 2)
   if (!fast) return launch_wave2<1, false, 2, 1>(a, s);
   if (a.wave_pol == 2) return launch_wave2<1, true, 3, 2>(a, s);

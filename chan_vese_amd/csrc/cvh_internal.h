@@ -109,6 +109,7 @@ struct CvhStepArgs {
   int wave_depth;                // wave kernel: rows of u kept in flight per lane (4 or 8)
   int wave_sync;                 // wave kernel: workgroup barrier every 4 rows
   int wave_prio;                 // progress-based s_setprio in the wave kernel
+  int state32;                   // 2-pixel wave kernel: the level set lives in HBM as float (option "state" = 32; u_in / u_out then point at floats)
   int near_switch;               // FAST wave / resident kernels: a wave that met near-field pixels runs its next group of rows in the table form of H_eps
   int wave_lds_cap;              // pad the LDS request so that at most wave_minw workgroups fit a CU
   CvhChainAcc *chain;            // chain mode (2-pixel wave kernel, FAST): fixed-point sum sets, or null
@@ -201,6 +202,8 @@ hipError_t cvh_launch_checkerboard(const double *sv, double *u, int h, int w, hi
 hipError_t cvh_launch_image_sums(const uint8_t *const *planes, int channels, size_t n, unsigned long long *out /* [2 * channels], zeroed */,
                                  hipStream_t s);
 hipError_t cvh_launch_mask(const double *u, uint8_t *mask, size_t n, int invert, hipStream_t s);
+hipError_t cvh_launch_state_narrow(double *u, float *uf, size_t n, hipStream_t s);       // uf = (float)u, u = (double)uf
+hipError_t cvh_launch_state_widen(const float *uf, double *u, size_t n, hipStream_t s);  // u = (double)uf
 hipError_t cvh_launch_ppf(double *data, size_t n, int op, double eps, hipStream_t s);
 hipError_t cvh_launch_separate(const uint8_t *img3, const double *u, uint8_t *sel3, size_t n,
                                int invert, hipStream_t s);

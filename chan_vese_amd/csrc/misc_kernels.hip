@@ -146,6 +146,31 @@ hipError_t cvh_launch_contour(const double *u, uint8_t *out, int h, int w, hipSt
   return hipGetLastError();
 }
 
+// FP32-state mode (option "state" = 32): the float buffers take over a level set (rounded to nearest even; the double copy is rewritten
+// with the rounded values), and the double mirror is refreshed from them for get / mask / contour / selection / the initial sums.
+__global__ void state_narrow_kernel(double *u, float *uf, size_t n)
+{
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const float f = (float)u[q];
+    uf[q] = f;
+    u[q] = (double)f;
+  }
+}
+__global__ void state_widen_kernel(const float *uf, double *u, size_t n)
+{
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) u[q] = (double)uf[q];
+}
+hipError_t cvh_launch_state_narrow(double *u, float *uf, size_t n, hipStream_t s)
+{
+  hipLaunchKernelGGL(state_narrow_kernel, dim3((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), dim3(256), 0, s, u, uf, n);
+  return hipGetLastError();
+}
+hipError_t cvh_launch_state_widen(const float *uf, double *u, size_t n, hipStream_t s)
+{
+  hipLaunchKernelGGL(state_widen_kernel, dim3((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), dim3(256), 0, s, uf, u, n);
+  return hipGetLastError();
+}
+
 hipError_t cvh_launch_mask(const double *u, uint8_t *mask, size_t n, int invert, hipStream_t s)
 {
   hipLaunchKernelGGL(mask_kernel, dim3(flat_grid(n)), dim3(256), 0, s, u, mask, n, invert);

@@ -43,4 +43,43 @@ __device__ __forceinline__ void buf_store_f64x2(double2_t v, __amdgpu_buffer_rsr
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, POL == 1 ? 16 : 0);
 }
 
+// The level set as it lives in HBM (option "state"): FP64 (the reference's CV_64FC1, src/main.cpp:225 -- the default and the parity
+// mode) or, DECLARED, FP32: 9 instead of 17 bytes per pixel-iteration, every new value rounded to float before it is stored and before
+// H_eps of it is summed; arithmetic, tables and sums stay FP64 / 64-bit fixed point.  StateIO<ST32, POL> moves a lane's pair of
+// adjacent values (and the one east-extra value) in that format; the LDS ring and every register of the march hold doubles.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <bool ST32, int POL>
+struct StateIO {
+  using raw2_t = double2_t;          // a lane's pair as loaded
+  using raw1_t = double;
+  static constexpr unsigned kBytes = 8u;
+  static __device__ __forceinline__ raw2_t load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return buf_load_f64x2<POL>(r, voff, soff); }
+  static __device__ __forceinline__ raw1_t load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return buf_load_f64(r, voff, soff); }
+  static __device__ __forceinline__ double2_t widen(raw2_t v) { return v; }
+  static __device__ __forceinline__ double widen(raw1_t v) { return v; }
+  static __device__ __forceinline__ double stored(double v) { return v; }                      // the value a later load returns
+  static __device__ __forceinline__ void store2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { buf_store_f64x2<POL>(v, r, voff, soff); }
+};
+template <int POL>
+struct StateIO<true, POL> {
+  using raw2_t = float2_t;
+  using raw1_t = float;
+  static constexpr unsigned kBytes = 4u;
+  static __device__ __forceinline__ raw2_t load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+  {
+    return __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, POL == 1 ? 1 : (POL == 2 ? 2 : 0)));
+  }
+  static __device__ __forceinline__ raw1_t load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+  {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  }
+  static __device__ __forceinline__ double2_t widen(raw2_t v) { return double2_t{(double)v.x, (double)v.y}; }
+  static __device__ __forceinline__ double widen(raw1_t v) { return (double)v; }
+  static __device__ __forceinline__ double stored(double v) { return (double)(float)v; }       // round to nearest even, as the store does
+  static __device__ __forceinline__ void store2(double2_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+  {   // (an 8-byte store: outside the wide-store data hazard of DESIGN.md 4.1)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, float2_t{(float)v.x, (float)v.y}), r, voff, soff, POL == 1 ? 16 : 0);
+  }
+};
+
 }  // namespace cvh_dev

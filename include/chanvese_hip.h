@@ -106,6 +106,12 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while ONE context's ping-pong
  *                    pair fits the Infinity Cache, <= 300 MB), 0 plain, 1 write-through; a caller that keeps several
  *                    contexts busy on one GPU should set 0
+ *   "state"          64 (default): the level set lives in HBM as double -- the reference's CV_64FC1 (src/main.cpp:225), the parity mode.
+ *                    32: a DECLARED fast mode that deliberately departs from the reference's type: float in HBM (9 instead of 17 bytes
+ *                    per pixel-iteration; 11 instead of 19 with three channels), every new value rounded to float; arithmetic, tables
+ *                    and the fixed-point sums unchanged.  2-pixel wave kernel only: FAST arithmetic, width a multiple of 16 and >= 144,
+ *                    fewer than 2^28 pixels (CVH_ERR_ARG otherwise).  cvh_set_levelset / cvh_get_levelset keep exchanging doubles.
+ *                    Parity bar: mask IoU >= 0.999 and median |du| / max|u| <= 1e-4 against the FP64 path
  *   "near_switch"    1 (default): a wave whose strip / band starts where most pixels are below the far-field threshold of H_eps (32 eps)
  *                    evaluates the table form of H_eps on every pixel of that strip (one form per pixel: a level set that is near
  *                    everywhere, e.g. dt << 1); 0: the far-field series with the per-group correction everywhere

@@ -200,7 +200,7 @@ def test_config5_batch_of_eight_interleaved(capi, oracle):
             ctx.set_image([imgs[b]])
             ctx.init_checkerboard()
             ctxs.append(ctx)
-        assert ctxs[0].launch_info()["kernel"] == "csv_wave2_kernel<1, true, 3, 0>"
+        assert ctxs[0].launch_info()["kernel"] == "csv_wave2_kernel<1, true, 3, 0, false>"
         for ctx in ctxs:
             ctx.enqueue_steps(6)
         done, _, stopped = ctxs[3].sync()
@@ -389,6 +389,73 @@ def test_config3_4096_300_iterations_against_the_fixture(capi, oracle, golden_di
     check_against_fullsize_fixture(np.load(os.path.join(golden_dir, "c3_4096_300.npz")), u_g, tr_g, m_g, steps)
 
 
+def state32_stats(u_g, u_c, umax):
+    """SURVEY.md 8(d) bar of the FP32-state mode: median |du| / max|u| <= 1e-4; p99 and the maximum are reported (a per-pixel maximum is
+    meaningless there: the survey's probe saw 49 % on isolated pixels with 0 mask flips)."""
+    d = np.abs(u_g - u_c).ravel() / umax
+    return float(np.median(d)), float(np.percentile(d, 99)), float(d.max())
+
+
+def test_state32_configs_1_and_4_against_the_oracle(capi, oracle):
+    """FP32-state mode on BASELINE configs[0] (512^2, 100 iterations) and configs[3] (2048^2: Perona-Malik 1000 steps, then 200 iterations on
+    the smoothed plane; the oracle leg is test_config4_configured_length's): IoU >= 0.999, median |du| / max|u| <= 1e-4."""
+    n = 512
+    img = synth.config_planes("C1", n)
+    u_c, done, _, _ = oracle.csv_run(img, oracle.checkerboard(n, n), oracle.make_params(tol=0), 100)
+    with capi.Context(n, n, 1, capi.make_params(tol=0)) as ctx:
+        ctx.set_option("state", 32)
+        ctx.set_image(img)
+        ctx.init_checkerboard()
+        assert ctx.run(100)[0] == 100
+        u_g, m_g = ctx.get_levelset(), ctx.get_mask()
+    med, p99, mx = state32_stats(u_g, u_c, np.abs(u_c).max())
+    print(f"state 32, C1 512^2 x 100: median {med:.2e}, p99 {p99:.2e}, max {mx:.2e} of max|u|; mask flips {int((m_g != oracle.mask(u_c)).sum())}")
+    assert med <= 1e-4 and iou(m_g, oracle.mask(u_c)) >= 0.999
+    n = 2048
+    img = synth.config_planes("C4", n)
+    if "c4" not in _ORACLE_LEGS:
+        pm_c = oracle.perona_malik(img, 30.0, 0.25, 250.0)
+        u_c, done_c, nrm_c, tr_c = oracle.csv_run(pm_c, oracle.checkerboard(n, n), oracle.make_params(tol=0), 200)
+        _ORACLE_LEGS["c4"] = (pm_c, u_c, tr_c)
+    pm_c, u_c, tr_c = _ORACLE_LEGS["c4"]
+    with capi.Context(n, n, 1, capi.make_params(tol=0)) as ctx:
+        ctx.set_option("state", 32)
+        ctx.set_image(pm_c)
+        ctx.init_checkerboard()
+        assert ctx.launch_info()["kernel"] == "csv_wave2_kernel<1, true, 3, 1, true>"
+        assert ctx.run(200)[0] == 200
+        u_g, m_g = ctx.get_levelset(), ctx.get_mask()
+    med, p99, mx = state32_stats(u_g, u_c, np.abs(u_c).max())
+    print(f"state 32, C4 2048^2 x 200: median {med:.2e}, p99 {p99:.2e}, max {mx:.2e} of max|u|; mask flips {int((m_g != oracle.mask(u_c)).sum())}")
+    assert med <= 1e-4 and iou(m_g, oracle.mask(u_c)) >= 0.999
+
+
+@pytest.mark.parametrize("cfg,stem,steps", [("C2", "c2_4096_500", 500), ("C3", "c3_4096_300", 300)])
+def test_state32_configs_2_and_3_against_the_fixture(capi, oracle, golden_dir, cfg, stem, steps):
+    """FP32-state mode on BASELINE configs[1] / [2] at their configured length against the FP64 oracle fixture: the statistics over the
+    fixture's level-set samples (stride-16 grid + eight full rows: 98 k pixels), the mask against the oracle's packed mask."""
+    n = 4096
+    fx = np.load(os.path.join(golden_dir, stem + ".npz"))
+    pk = dict(tol=0) if cfg == "C2" else dict(tol=0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1])
+    planes = synth.config_planes(cfg, n)
+    with capi.Context(n, n, len(planes), capi.make_params(**pk)) as ctx:
+        ctx.set_option("state", 32)
+        ctx.set_image(planes)
+        ctx.init_checkerboard()
+        assert ctx.launch_info()["kernel"].endswith("true>")
+        assert ctx.run(steps)[0] == steps
+        u_g, m_g = ctx.get_levelset(), ctx.get_mask()
+    oi, oj, st = (int(v) for v in fx["grid_offset_stride"])
+    rows = [int(r) for r in fx["rows_index"]]
+    got = np.concatenate([u_g[oi::st, oj::st].ravel(), u_g[rows].ravel()])
+    want = np.concatenate([fx["grid_ref"].ravel(), fx["rows_ref"].ravel()])
+    med, p99, mx = state32_stats(got, want, float(fx["umax_ref"][0]))
+    m_o = np.unpackbits(fx["mask_bits_ref"]).reshape(n, n).astype(bool)
+    flips = int((m_g.astype(bool) != m_o).sum())
+    print(f"state 32, {cfg} 4096^2 x {steps}: median {med:.2e}, p99 {p99:.2e}, max {mx:.2e} of max|u| over {got.size} samples; mask flips {flips}")
+    assert med <= 1e-4 and iou(m_g, m_o) >= 0.999
+
+
 @pytest.mark.parametrize("shape", [(1, 144), (144, 1), (3, 700), (100, 517), (150, 530), (9, 272), (64, 2016)])
 @pytest.mark.parametrize("mode,math", [("strict", 1), ("fast", 2)])
 def test_csv_three_channel_edge_shapes(capi, oracle, shape, mode, math):
@@ -495,7 +562,7 @@ def test_kernel_flavours_agree_at_4096(capi):
 
 def test_two_pixel_kernel_beyond_the_cache_policy_switch(capi):
     """4608^2: the footprint (361 MB) is above the 300 MB switch, so the 2-pixel kernel runs its plain-store flavour
-    (csv_wave2_kernel<1, true, 3, 0>) by default -- compared with the 1-pixel kernel, GPU vs GPU, 3 iterations
+    (csv_wave2_kernel<1, true, 3, 0, false>) by default -- compared with the 1-pixel kernel, GPU vs GPU, 3 iterations
     (the store-data hazard only showed under memory back-pressure, and every flavour has its own register allocation)."""
     n = 4608
     planes = [synth.disk(n)]
@@ -513,7 +580,7 @@ def test_two_pixel_kernel_beyond_the_cache_policy_switch(capi):
 
     ref, _ = run(dict(kernel=2))
     got, info = run({})
-    assert info["kernel"] == "csv_wave2_kernel<1, true, 3, 0>", info
+    assert info["kernel"] == "csv_wave2_kernel<1, true, 3, 0, false>", info
     assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
 
 

@@ -122,7 +122,7 @@ def test_launch_info_names_what_runs(capi):
         assert ctx.launch_info()["kernel"] == "csv_resident_kernel<4>"       # the default for a plane that fits the chip's LDS: 32 x 8 tiles of 32 rows, 4 per wave
         ctx.set_option("resident", 0)
         i = ctx.launch_info()
-        assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"
+        assert i["kernel"] == "csv_wave2_kernel<1, true, 3, 1, false>" and int(i["grid"]) > 1 and i["chain"] == "1" and i["math"] == "fast"
         ctx.set_option("kernel", 2)
         assert ctx.launch_info()["kernel"].startswith("csv_wave_kernel<1, true, true, 5, true, 1, 1>")
         ctx.set_option("math_mode", 1)

