@@ -247,10 +247,8 @@ def main():
             ctx.set_option("math_mode", math_mode)
             ctx.set_option("finalize", args.finalize)
             ctx.set_option("state", state_bits)
-            if images > 1 and C == 1:
-                # several images share the GPU: their level sets (8 x 272 MiB) do not live in the Infinity Cache, where write-through
-                # stores cost (cache policy; measured 292.6-293.5 k vs 288.3-289.3 k Mpx-it/s)
-                ctx.set_option("wave_pol", 0)
+            # (several images on one GPU: their level sets -- 8 x 272 MiB -- do not live in the Infinity Cache, where write-through stores
+            # cost.  Rounds 2-3 set "wave_pol" = 0 here by hand; since round 4 the library's automatic choice sees every live context.)
             for kv in args.opt:
                 k, v = kv.split("=")
                 ctx.set_option(k, int(v))
@@ -312,6 +310,7 @@ def main():
         if scratch is None:
             scratch = capi.Context(n, n, C, capi.make_params(tol=0.0, dt=CONFIG_DT.get(name, 1.0)), device=device)
             scratch.set_option("math_mode", math_mode)
+            scratch.set_option("co_resident", 0)      # a warm-up context: idle while the measured contexts stream (not part of the device's live footprint)
             scratch.set_option("state", state_bits)
             for kv in args.opt:
                 k, v = kv.split("=")

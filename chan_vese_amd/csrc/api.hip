@@ -36,6 +36,7 @@ struct cvh_context {
   // context on this device that holds an image and a level set (live_footprint), and kept until the run counter is reset
   int co_resident = 1;          // option "co_resident": 0 = a scratch / warm-up context that does not stream beside the others
   mutable int run_pol = -1;     // the decision of the current run (-1: not taken yet)
+  mutable int run_alone = -1;   // 1: no other co-resident context on the device when the run started (automatic resident flow allowed)
   CvhState *d_state = nullptr;
   CvhState *h_state = nullptr;  // pinned, four slots for pipelined polling
   double *d_partials = nullptr;
@@ -184,6 +185,15 @@ static double live_footprint(const cvh_context *c);
 
 // bytes per pixel-iteration pair (level-set ping-pong + planes) of every context on c's device that holds an image and a level set and
 // streams beside the others ("co_resident")
+static int live_contexts(const cvh_context *c)
+{
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  int k = 0;
+  for (const cvh_context *o : g_live)
+    if (o->device == c->device && o->co_resident && ((o->have_u && o->have_image) || o == c)) ++k;
+  return k;
+}
+
 static double live_footprint(const cvh_context *c)
 {
   std::lock_guard<std::mutex> lk(g_live_mu);
@@ -786,6 +796,14 @@ static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
   // resident vs per-launch: 128^2 7.4 vs 7.6 us, 256^2 6.9 vs 7.6, 768^2 8.5 vs 9.8, 1024x2048 11.5 vs 14.6, 1536^2 12.4 vs 16.2,
   // 1200x1920 12.0 vs 15.4, 2048^2 16.0 vs 20.9: ahead at every size that fits)
   if (c->resident_opt < 0 && (c->kernel != -1 || c->strip_rows != 0 || c->strips != 0 || !c->use_graph)) return false;
+  // auto also steps aside when other contexts stream on this GPU (a batch): cooperative launches of different contexts serialise and cost
+  // ~25 us each, while interleaved per-launch flows fill each other's gaps -- measured, eight images interleaved in chunks of 8 iterations
+  // (tools/batch_probe.py, gpurun_out/r4s9): 2048^2 32.6 us per image-iteration resident vs 16.2 per launch (17.3 with chunks of 50);
+  // 1024^2 22.3 vs 6.1 (10.6).  Decided when a run's first iteration is enqueued, kept for the run.
+  if (c->resident_opt < 0) {
+    if (c->run_alone < 0 || c->enqueued == 0) c->run_alone = live_contexts(c) <= 1 ? 1 : 0;
+    if (!c->run_alone) return false;
+  }
   if (c->resident_cap < 0) {
     int coop = 0;
     c->resident_cap = 0;
@@ -1021,6 +1039,24 @@ extern "C" int cvh_debug_strip_bounds(int kind, int h, int tiles_x, int S, int s
   std::vector<int> b;
   compute_strip_bounds(kind, h, tiles_x, S, strip_rows, nblocks, cls, cskew, skew, b);
   memcpy(out, b.data(), b.size() * sizeof(int));
+  return CVH_OK;
+}
+
+// Diagnostic (not part of include/chanvese_hip.h): which per-launch data flow resolve_geometry() picks for a shape and option set, without a
+// device -- 0 tile kernel, 2 wave kernel, 3 wave kernel with 2 pixels per lane -- and its grid (tests/test_host_geometry.py pins the dispatch,
+// e.g. the tile kernel from 2^28 pixels on, which no GPU test launches).
+extern "C" int cvh_debug_data_flow(int h, int w, int channels, int math_mode, int kernel, int state_bits, int num_cus, int *flow, int *tiles_x,
+                                   int *tiles_y, int *strip_rows)
+{
+  if (h < 1 || w < 1 || (channels != 1 && channels != 3) || !flow) return CVH_ERR_ARG;
+  cvh_context c;
+  c.h = h; c.w = w; c.C = channels; c.n = (size_t)h * (size_t)w;
+  c.math_mode = math_mode; c.kernel = kernel; c.state_bits = state_bits; c.num_cus = num_cus > 0 ? num_cus : 256;
+  const Geometry g = resolve_geometry(&c);
+  *flow = g.strip;
+  if (tiles_x) *tiles_x = g.tiles_x;
+  if (tiles_y) *tiles_y = g.tiles_y;
+  if (strip_rows) *strip_rows = g.strip_rows;
   return CVH_OK;
 }
 

@@ -48,10 +48,6 @@ struct WaveSmem {
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
 
-#ifndef CVH_STORE_MOD
-#define CVH_STORE_MOD ""
-#endif
-
 // POL: cache policy of the level-set stores (1 = sc1 write-through while the pair fits the Infinity Cache: 1000^2 12.4 -> 11.65 us; beyond
 // it write-through costs -- 6144^2: 144 -> 171 us; wave2_device.h has the 2-pixel kernel's figures), chosen by the host (wave_pol)
 template <int C, bool FAST, bool LUT, int MINW, bool IMGV, int G, int POL = 0>

@@ -20,9 +20,6 @@ __device__ __forceinline__ double fma3(double a, double b, double c)
 
 // Coefficients of the far-field series with eps and 1/pi folded in (wave-uniform).
 struct FarCoef { double k0, k1, k2, k3, k4, thr; };
-#ifndef CVH_FAR_TERMS
-#define CVH_FAR_TERMS 5
-#endif
 
 // H_eps(u) - 1/2 = copysign(atan(|u|/eps)/pi, u).  The sums carry this CENTRED value (the
 // finalisation adds N/2 and sum(I)/2, exact integers or half-integers): one addition less per pixel.
@@ -32,7 +29,7 @@ struct FarCoef { double k0, k1, k2, k3, k4, thr; };
 // series of atan(t), t = eps/|u| <= 1/32, truncated after t^9/9 (next term < 2.5e-18) needs one
 // reciprocal and no table.  With r = 1/|u|:
 //   atan(eps r)/pi = r (k0 + r^2 (k1 + r^2 (k2 + r^2 (k3 + r^2 k4)))), k_i = (-1)^i eps^(2i+1)/((2i+1) pi).
-// (-DCVH_FAR_TERMS=4 with the option far_terms = 4: the 4-term series from 64 eps, one FMA less per pixel.)
+// (The diagnostic option far_terms = 4 zeroes k4 and moves the threshold to 64 eps: round 1's 4-term series.)
 // The argument is CLAMPED to the far field so that the formula stays finite on every lane: the
 // march evaluates it unconditionally (no branch inside a row: a group of 4 rows is one basic block
 // and hipcc overlaps the rows' dependent chains), and the rare lanes with |u| below the threshold are
@@ -43,12 +40,8 @@ __device__ __forceinline__ double heaviside_centred_far(double u, const FarCoef 
   const double r0 = __builtin_amdgcn_rcp(au);
   const double r = __builtin_fma(__builtin_fma(-au, r0, 1.0), r0, r0);
   const double r2 = r * r;
-#if CVH_FAR_TERMS == 5
   double p = fma3(r2, fc.k4, fc.k3);
   p = fma3(p, r2, fc.k2);
-#else
-  double p = fma3(r2, fc.k3, fc.k2);
-#endif
   p = fma3(p, r2, fc.k1);
   p = fma3(p, r2, fc.k0);
   return __builtin_copysign(__builtin_fma(-r, p, 0.5), u);

@@ -102,10 +102,14 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *                    at most one 128 x 128 tile per CU: up to 2048 x 2048 on an MI355X) iterate IN LDS -- one cooperative launch per
  *                    chunk of iterations, one workgroup per tile, a grid barrier per iteration, the stop rule inside the kernel at the
  *                    reference's iteration (csv_resident_kernel.hip).  Auto steps aside when "kernel", "strip_rows", "strips" or
- *                    "graph" were set (the caller asked for a per-launch flow)
- *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while ONE context's ping-pong
- *                    pair fits the Infinity Cache, <= 300 MB), 0 plain, 1 write-through; a caller that keeps several
- *                    contexts busy on one GPU should set 0
+ *                    "graph" were set (the caller asked for a per-launch flow), when "state" is 32, and when other co-resident
+ *                    contexts live on the device (a batch: cooperative launches of different contexts serialise; interleaved
+ *                    per-launch flows are twice as fast there)
+ *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while the ping-pong pairs and planes of
+ *                    ALL contexts on the device that hold an image and a level set fit the Infinity Cache, <= 300 MB together; decided
+ *                    when a run's first iteration is enqueued, kept for the run), 0 plain, 1 write-through
+ *   "co_resident"    1 (default): this context streams beside the others on its GPU and counts in their automatic choices ("wave_pol",
+ *                    "resident"); 0: a scratch / warm-up context that is idle while the others run
  *   "state"          64 (default): the level set lives in HBM as double -- the reference's CV_64FC1 (src/main.cpp:225), the parity mode.
  *                    32: a DECLARED fast mode that deliberately departs from the reference's type: float in HBM (9 instead of 17 bytes
  *                    per pixel-iteration; 11 instead of 19 with three channels), every new value rounded to float; arithmetic, tables

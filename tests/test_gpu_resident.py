@@ -153,3 +153,33 @@ def test_resident_straight_line_flavours_are_the_generic_march_bit_for_bit(capi,
             assert ctx.run(25)[0] == 25
             outs.append((ctx.get_levelset(), ctx.get_trace(25)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_automatic_flow_steps_aside_for_a_batch(capi, oracle):
+    """Round 4: the automatic choice of the resident flow looks at the device's live contexts.  One 256^2 context alone: the resident kernel.
+    Two contexts that hold an image and a level set (a batch): cooperative launches of different contexts would serialise (tools/batch_probe.py:
+    32.6 vs 16.2 us per image-iteration at 2048^2), so a run that starts then takes the per-launch flow; a scratch context ("co_resident" = 0)
+    does not count; results agree with the oracle either way."""
+    n = 256
+    imgs = [synth.disk(n, 200, 50, noise=6, seed=s) for s in (3, 4)]
+    u0 = oracle.checkerboard(n, n)
+    a = capi.Context(n, n, 1, capi.make_params(tol=0))
+    a.set_image([imgs[0]]); a.set_levelset(u0)
+    assert a.launch_info()["kernel"].startswith("csv_resident_kernel<")
+    b = capi.Context(n, n, 1, capi.make_params(tol=0))
+    b.set_option("co_resident", 0)
+    b.set_image([imgs[1]]); b.set_levelset(u0)
+    assert a.launch_info()["kernel"].startswith("csv_resident_kernel<")          # b is a scratch context
+    b.set_option("co_resident", 1)
+    assert a.launch_info()["kernel"].startswith("csv_wave") and b.launch_info()["kernel"].startswith("csv_wave")
+    for _ in range(2):
+        a.enqueue_steps(5); b.enqueue_steps(5)
+    for c, im in ((a, imgs[0]), (b, imgs[1])):
+        done, _, stopped = c.sync()
+        assert done == 10 and not stopped
+        u_c, _, _, _ = oracle.csv_run([im], u0, oracle.make_params(tol=0), 10)
+        assert np.abs(c.get_levelset() - u_c).max() <= 1e-9 * np.abs(u_c).max()
+    b.close()
+    a.set_levelset(u0)                                                            # a new run, alone again
+    assert a.launch_info()["kernel"].startswith("csv_resident_kernel<")
+    a.close()

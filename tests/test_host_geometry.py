@@ -64,3 +64,32 @@ def test_strip_table_covers_the_image(kind, h, tiles_x, S, strip_rows, nb, cls, 
     b = bounds(kind, h, tiles_x, S, strip_rows, nb, cls, cskew)
     assert b[0] == 0 and b[-1] == h and np.all(np.diff(b) >= 0)      # monotone cover of rows [0, h): the kernels' exit test relies on it
     assert len(b) == S + 1
+
+
+def data_flow(h, w, channels=1, math_mode=2, kernel=-1, state=64, cus=256):
+    L = capi.lib()
+    fn = L.cvh_debug_data_flow
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)] * 4
+    out = [C.c_int(-1) for _ in range(4)]
+    assert fn(h, w, channels, math_mode, kernel, state, cus, *[C.byref(o) for o in out]) == 0
+    return tuple(o.value for o in out)          # (flow, tiles_x, tiles_y, strip_rows)
+
+
+def test_which_per_launch_flow_runs():
+    """resolve_geometry() (api.hip) on the host: 3 = wave kernel with 2 pixels per lane, 2 = wave kernel, 0 = tile kernel.  The wave
+    kernels address the level set with 32-bit byte offsets and mark dropped lanes with offset 2^31, so planes of 2^28 pixels (2 GiB of
+    level set) or more take the tile kernel -- a dispatch no GPU test launches (a 2 GiB level-set pair + planes per context)."""
+    assert data_flow(4096, 4096)[0] == 3                              # BASELINE configs[1]
+    assert data_flow(4096, 4096, channels=3)[0] == 3                  # configs[2], FAST
+    assert data_flow(4096, 4096, channels=3, math_mode=1)[0] == 2     # STRICT three channels: 1-pixel kernel
+    assert data_flow(4096, 4100)[0] == 2                              # width not a multiple of 16
+    assert data_flow(512, 512)[0] == 2                                # below 0.6 Mpixel (where the resident flow does not take over)
+    assert data_flow(512, 512, kernel=3)[0] == 3 and data_flow(512, 512, state=32)[0] == 3      # on request / FP32 state
+    assert data_flow(16384, 16368)[0] == 3                            # 2^28 - 2^18 pixels: still the wave kernel
+    assert data_flow(16384, 16384)[0] == 0                            # 2^28 pixels: the tile kernel
+    assert data_flow(16384, 16384, kernel=3)[0] == 0 and data_flow(16384, 16384, kernel=2)[0] == 0 and data_flow(20000, 20000, channels=3)[0] == 0
+    flow, tx, ty, rows = data_flow(16384, 16384)
+    assert tx * ty > 0 and rows in (14, 16) and ty * rows >= 16384    # the tile grid covers the plane
+    # the bench geometry: 33 wave-columns of 126, 90 strips (tests above pin the strip table itself)
+    assert data_flow(4096, 4096)[1:3] == (33, 90)
