@@ -15,7 +15,7 @@
 // --line-color, one frame for t = 0 and one after every iteration, :926-931,:997); the overlay
 // text of -O is not rendered (no font rasteriser here), --fps has nothing to act on.
 // Additions that do not collide with reference options: --dump-u, --dump-mask, --device, --math,
-// --rect, --circ, --verbose.
+// --state, --rect, --circ, --verbose.
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
@@ -168,7 +168,7 @@ const Spec kSpecs[] = {
     {"segment", 'S', 0}, {"grayscale", 'g', 0}, {"video", 'V', 0}, {"overlay-text", 'O', 0},
     {"invert-selection", 'I', 0}, {"select", 's', 0}, {"rectangle", 'R', 0}, {"circle", 'C', 0},
     // additions of this build
-    {"dump-u", 0, 1}, {"dump-mask", 0, 1}, {"device", 0, 1}, {"math", 0, 1}, {"rect", 0, 1}, {"circ", 0, 1}, {"verbose", 0, 0}};
+    {"dump-u", 0, 1}, {"dump-mask", 0, 1}, {"device", 0, 1}, {"math", 0, 1}, {"state", 0, 1}, {"rect", 0, 1}, {"circ", 0, 1}, {"verbose", 0, 0}};
 
 struct Parsed {
   std::vector<std::pair<std::string, std::vector<std::string>>> opts;
@@ -298,6 +298,7 @@ void print_help()
       "  --dump-mask arg                    write the final mask ((float)u > 0) as PGM or PNG by extension (0/255)\n"
       "  --device arg (=0)                  HIP device\n"
       "  --math arg (=fast)                 strict | fast (see include/chanvese_hip.h)\n"
+      "  --state arg (=64)                  64 | 32: level set kept as double (the reference's CV_64FC1) or, DECLARED, as float in GPU memory\n"
       "  --verbose                          print the iteration count and last norm to stderr\n"
       "\n";
 }
@@ -340,6 +341,8 @@ int main(int argc, char **argv)
   if (auto v = one("dump-mask")) dump_mask = *v;
   if (auto v = one("device")) device = to_int("device", *v);
   if (auto v = one("math")) math = *v;
+  int state_bits = 64;
+  if (auto v = one("state")) state_bits = to_int("state", *v);
   if (auto v = one("rect")) rect = *v;
   if (auto v = one("circ")) circ = *v;
   segment = vm.count("segment"); grayscale = vm.count("grayscale"); write_video = vm.count("video");
@@ -388,6 +391,7 @@ int main(int argc, char **argv)
     msg_exit("Interactive contour selection (-R/-C) needs a display and is not supported in this build; use --rect x,y,w,h or --circ cx,cy,r.");
   if (!rect.empty() && !circ.empty()) msg_exit("Cannot initialize with both rectangular and circular contour");
   if (math != "strict" && math != "fast") msg_exit("error: the argument ('" + math + "') for option '--math' is invalid");
+  if (state_bits != 64 && state_bits != 32) msg_exit("error: the argument ('" + std::to_string(state_bits) + "') for option '--state' is invalid");
 
   // ---- read the image: src/main.cpp:877-887 (8-bit gray or BGR)
   Image file;
@@ -431,6 +435,7 @@ int main(int argc, char **argv)
   if (cvh_create(&ctx, h, w, nof_channels, &prm, device) != CVH_OK)
     msg_exit(std::string("Error: cannot initialise the HIP backend: ") + cvh_last_error(nullptr));
   cvh_check(ctx, cvh_set_option(ctx, "math_mode", math == "strict" ? CVH_MATH_STRICT : CVH_MATH_FAST), "math_mode");
+  if (state_bits == 32) cvh_check(ctx, cvh_set_option(ctx, "state", 32), "state");   // declared FP32-state mode: never the default
   {
     std::vector<const uint8_t *> pp;
     for (auto &p : planes) pp.push_back(p.data());

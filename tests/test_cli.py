@@ -329,3 +329,27 @@ def test_cli_video_frames(cli, oracle, tmp_path):
     _, done, _, _ = oracle.csv_run([img], oracle.checkerboard(h, w), oracle.make_params(tol=0.5), 10 ** 6)
     assert f"{done} iterations" in r.stderr
     assert len(os.listdir(tmp_path / "v2_frames")) == done + 1
+
+
+@pytest.mark.gpu
+def test_cli_state_32_is_a_declared_switch(cli, oracle, tmp_path):
+    """--state 32 (build-only addition): the declared FP32-state mode of the C ABI through the CLI -- same outputs as the default run up to the
+    survey's statistical bar (mask equal, median |du| / max|u| <= 1e-4); widths the 2-pixel kernel cannot take and other values are refused."""
+    h, w = 96, 160
+    img = synth.disk(96, 200, 50, noise=10, seed=9, h=h, w=w)
+    write_pgm(tmp_path / "a.pgm", img)
+    us = {}
+    for st in ("64", "32"):
+        r = run(cli, "-i", str(tmp_path / "a.pgm"), "-g", "-N", "40", "-t", "0", "--state", st, "--dump-u", str(tmp_path / f"u{st}.bin"),
+                "--dump-mask", str(tmp_path / f"m{st}.pgm"))
+        assert r.returncode == 0, r.stderr
+        us[st] = np.fromfile(tmp_path / f"u{st}.bin", dtype=np.float64).reshape(h, w)
+    u_c, _, _, _ = oracle.csv_run([img], oracle.checkerboard(h, w), oracle.make_params(tol=0), 40)
+    assert np.abs(us["64"] - u_c).max() <= 1e-6 * np.abs(u_c).max()
+    assert np.array_equal(us["32"], us["32"].astype(np.float32).astype(np.float64))            # floats
+    assert np.median(np.abs(us["32"] - u_c)) <= 1e-4 * np.abs(u_c).max()
+    assert np.array_equal(read_pnm(tmp_path / "m32.pgm"), read_pnm(tmp_path / "m64.pgm"))
+    write_pgm(tmp_path / "b.pgm", synth.disk(64, 200, 50, h=64, w=100))
+    assert run(cli, "-i", str(tmp_path / "b.pgm"), "-g", "-N", "2", "--state", "32").returncode == 1      # width not a multiple of 16
+    r = run(cli, "-i", str(tmp_path / "a.pgm"), "-g", "--state", "16")
+    assert r.returncode == 1 and "option '--state' is invalid" in r.stderr
