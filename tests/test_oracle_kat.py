@@ -139,3 +139,38 @@ def test_stop_rule_breaks_after_update(oracle):
     u0 = oracle.checkerboard(64, 64)
     u, done, last, tr = oracle.csv_run([img], u0, p, 50)
     assert done == 1 and not np.array_equal(u, u0)
+
+
+def test_pm_linear_ramp_is_stationary_in_the_interior(oracle):
+    """Hand-derived: on I(i, j) = 3 j the Sobel pair is (gx, gy) = (24, 0) everywhere inside, so g is CONSTANT there and the four fluxes of
+    src/main.cpp:544-547 cancel exactly, g (3 - 3) + g (0 - 0) = 0: a pixel at least 2 * `steps` columns from the left / right border (where the clamped
+    neighbours and the g = 1 ring break the symmetry; a step reaches TWO pixels: g of a neighbour needs the neighbour's 3 x 3) keeps its value bit for bit."""
+    h, w, steps = 12, 60, 3
+    img = np.tile((3 * np.arange(w)).astype(np.uint8), (h, 1))
+    out, st = oracle.perona_malik([img], 30, 0.25, steps * 0.25, want_state=True)
+    assert oracle.pm_trip_count(0.25, steps * 0.25) == steps
+    inner = slice(2 * steps, w - 2 * steps)
+    assert np.array_equal(st[0][:, inner], img[:, inner].astype(np.float64))
+    assert np.all(st[0][:, 2 * steps - 1] != img[:, 2 * steps - 1]) and np.all(st[0][:, 0] != img[:, 0])      # exactly up to there it does move
+    assert np.array_equal(out[0][:, inner], img[:, inner])
+
+
+def test_csv_constant_level_set_is_analytic(oracle):
+    """Hand-derived: u == K (constant) has zero curvature (src/main.cpp:342-375), H_eps(K) is one number, so c1 = c2 = mean(I) (:272-280) and with
+    lambda1 = lambda2 the region term vanishes: one iteration moves every pixel by dt * delta_eps(K) * (-nu) (:985-994) -- nothing for nu = 0
+    (norm 0: the loop stops at once for any tol >= 0), a uniform shift otherwise; the norm is sqrt(h w) times that shift."""
+    h, w, K = 7, 9, 2.5
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    u = np.full((h, w), K)
+    nrm, c1, c2 = oracle.csv_step([img], u, oracle.make_params(tol=0))
+    assert nrm == 0.0 and np.array_equal(u, np.full((h, w), K))
+    assert abs(c1[0] - img.mean()) <= 1e-12 * img.mean() and abs(c2[0] - img.mean()) <= 1e-12 * img.mean()
+    u = np.full((h, w), K)
+    nu, dt, eps = -0.75, 0.5, 1.5
+    nrm, _, _ = oracle.csv_step([img], u, oracle.make_params(tol=0, nu=nu, dt=dt, eps=eps))
+    shift = dt * (-nu) * (eps / (np.pi * (eps * eps + K * K)))
+    assert np.allclose(u, K + shift, rtol=1e-15, atol=0) and abs(nrm - np.sqrt(h * w) * shift) <= 1e-14 * nrm
+    # the run stops at iteration 1 whatever the tolerance when nothing moves (:1000: norm <= stop_cond, 0 <= 0)
+    u_end, done, last, _ = oracle.csv_run([img], np.full((h, w), K), oracle.make_params(tol=0), 50)
+    assert done == 1 and last == 0.0
