@@ -575,3 +575,44 @@ def test_cache_policy_of_the_rows_does_not_change_results(capi, shape, channels,
     for o in out[1:]:
         assert o[2] == out[0][2] == 37 and o[3] == out[0][3]
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+
+
+@pytest.mark.parametrize("case", ["two_pixel_c1", "two_pixel_c3", "resident", "one_pixel_c3", "mixed_strips"])
+def test_all_near_regime(capi, oracle, case):
+    """Round 4: the regime of the reference README's second example (--dt 0.001: |u| stays below the far-field threshold of H_eps, 32 eps, for
+    the whole run), sustained over 25 iterations in every FAST flow -- the per-strip / per-band near-form march of the 2-pixel and resident
+    kernels ("near_switch", default), the same flows with it switched off (far series + per-group correction on every row), the 1-pixel
+    kernel -- against the oracle at 1e-9; "mixed_strips": the upper half of the plane far (|u| = 60), the lower half near, so strips of
+    both kinds and the strip the border runs through coexist in one launch."""
+    steps = 25
+    rng = np.random.default_rng(len(case))
+    if case == "resident":
+        shape, C, opts = (256, 256), 1, [dict(), dict(near_switch=0), dict(resident=0, kernel=3)]
+    elif case == "two_pixel_c1":
+        shape, C, opts = (150, 528), 1, [dict(kernel=3, resident=0), dict(kernel=3, resident=0, near_switch=0), dict(kernel=3, resident=0, strip_rows=8)]
+    elif case == "two_pixel_c3":
+        shape, C, opts = (150, 528), 3, [dict(kernel=3), dict(kernel=3, near_switch=0)]
+    elif case == "one_pixel_c3":
+        shape, C, opts = (100, 517), 3, [dict()]
+    else:
+        shape, C, opts = (192, 272), 1, [dict(kernel=3, resident=0), dict(kernel=3, resident=0, near_switch=0), dict()]
+    h, w = shape
+    planes = [synth.disk(min(h, w), 200 - 30 * k, 50 + 20 * k, noise=12, seed=7 + k, h=h, w=w) for k in range(C)]
+    u0 = oracle.checkerboard(h, w)
+    pk = dict(tol=0, dt=0.001, nu=-3.0)
+    if C == 3:
+        pk.update(lambda1=[1, 1, 0.1], lambda2=[1, 0.7, 1])
+    if case == "mixed_strips":
+        u0 = u0.copy()
+        u0[: h // 2] *= 60.0
+    u_c, done_c, nrm_c, tr_c = oracle.csv_run(planes, u0, oracle.make_params(**pk), steps)
+    if case != "mixed_strips":
+        assert np.abs(u_c).max() < 32.0          # the regime this test is about
+    else:
+        assert np.abs(u_c[1: h // 2 - 4, 1:]).min() > 32.0 and np.abs(u_c[h // 2 + 4:]).max() < 32.0     # (row 0 / column 0 of a checkerboard are zeros)
+    for o in opts:
+        u_g, done, nrm, tr_g, m_g = gpu_run(capi, planes, u0, steps, math=2, opts=o, **pk)
+        assert done == steps, o
+        assert rel_err(u_g, u_c) <= 1e-9, (o, rel_err(u_g, u_c))
+        assert np.allclose(tr_g, tr_c, rtol=1e-9, atol=0), o
+        assert np.array_equal(m_g, oracle.mask(u_c)), o
