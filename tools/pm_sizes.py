@@ -1,4 +1,4 @@
-"""Diagnostic: Perona-Malik step time by image size; options as key=value arguments (e.g. pm_kernel=2 pm_strip_rows=48)."""
+"""Diagnostic: Perona-Malik step time by image size; options as key=value arguments (e.g. pm_kernel=3 pm_strip_rows=48)."""
 import sys; sys.path.insert(0, '.')
 from chan_vese_amd import capi, synth
 opts = [kv.split("=") for kv in sys.argv[1:]]
