@@ -1063,14 +1063,19 @@ extern "C" int cvh_debug_data_flow(int h, int w, int channels, int math_mode, in
 static int upload_strip_bounds(cvh_context *c, const Geometry &g)
 {
   const int cls = (((g.strip == 3 && c->wave_cls) || (g.strip == 2 && c->wave_cls == 2)) && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
-  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip, c->h};
+  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip + (c->state_bits == 32 ? 500000000 : 0), c->h};
   if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
   std::vector<int> b;
   // The skew pays for short strips only (one process, 2-pixel kernel: 4096^2, 46 rows: 61.1 -> 58.7 us; 6144^2, 102 rows: 140.9 ->
   // 140.6; 8192^2 forced onto this kernel, 178 rows: 244 -> 285 us): full below 46 rows, fading to none at 128.
   int cskew = c->wave_cskew;
   if (g.strip_rows > 46) cskew = g.strip_rows >= 128 ? 0 : (int)(cskew * (128.0 - g.strip_rows) / (128.0 - 46.0));
-  if (c->C == 3 && c->wave_cskew == 500) cskew = 0;   // three channels: equal strips measured best (73.3 vs 74.1 us); any other "wave_cskew" applies as given
+  // three channels: round 3 measured equal strips best (73.3 vs 74.1 us with the full skew, with the workgroup barrier per group); without that
+  // barrier (their default since) the wave timeline shows the staircase again -- strips of dispatch round 0 end at 65 us, of round 2 at 74-76 -- and
+  // a skew of 0.425 wins: five alternations in one context (round 4, gpurun_out/r4s17) 73.00 (equal) / 71.69 (0.35) / 70.88 (0.425) / 71.74 (0.5 +
+  // priority scheme 2) us.  Any other "wave_cskew" applies as given.
+  // (the FP32-state flavour of three channels, compute-bound, still prefers equal strips: 52.5 vs 54.6 us, gpurun_out/r4s19)
+  if (c->C == 3 && c->wave_cskew == 500) cskew = c->state_bits == 32 ? 0 : 425;
   compute_strip_bounds(g.strip, c->h, g.tiles_x, g.tiles_y, g.strip_rows, g.nblocks, cls, cskew, c->wave_skew, b);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
   HIPCHK(c, hipMemcpy(c->d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));

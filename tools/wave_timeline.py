@@ -4,12 +4,13 @@ sys.path.insert(0, '.')
 import numpy as np
 from chan_vese_amd import capi, synth
 n = int(__import__("os").environ.get("N", "4096"))
-ctx = capi.Context(n, n, 1, capi.make_params(tol=0.0))
+C_ = int(__import__("os").environ.get("C", "1"))     # C=3: the 3-channel disks of config C3
+ctx = capi.Context(n, n, C_, capi.make_params(tol=0.0, lambda1=[1, 1, 0.5], lambda2=[1, 0.5, 1]) if C_ == 3 else capi.make_params(tol=0.0))
 ctx.set_option("kernel", int(__import__("os").environ.get("KERNEL", "2")))
 for kv in sys.argv[1:]:
     k, v = kv.split("="); ctx.set_option(k, int(v))
 ctx.set_option("debug_times", 1)
-ctx.set_image([synth.disk(n)]); ctx.set_levelset(capi.checkerboard_host(n, n))
+ctx.set_image(synth.config_planes("C3", n) if C_ == 3 else [synth.disk(n)]); ctx.set_levelset(capi.checkerboard_host(n, n))
 ctx.run(int(__import__('os').environ.get('ITERS', '5')))
 L = capi.lib()
 buf = np.zeros(2_000_000, dtype=np.uint64); words = C.c_long(0); nb = C.c_int(0)
