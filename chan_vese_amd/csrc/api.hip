@@ -600,6 +600,7 @@ static int reset_run_impl(cvh_context *c)
   c->chain_pb = (c->chain_pb + c->steps_done) & 3;
   c->steps_done = 0;
   c->enqueued = 0;
+  c->run_pol = -1; c->run_alone = -1;          // the automatic choices of a run are taken again (live-context registry)
   static const int zeros[4] = {0, 0, 0, 0};   // steps_done, stopped, ticket, pending
   HIPCHK(c, hipMemcpyAsync(&c->d_state->steps_done, zeros, sizeof(zeros), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(&c->d_chain->v[(c->chain_pb + 1) & 3][0], 0, sizeof(c->d_chain->v[0]), c->stream));
