@@ -194,6 +194,13 @@ static int live_contexts(const cvh_context *c)
   return k;
 }
 
+// Is this context the only co-resident one on its device?  Decided when a run's first iteration is enqueued, kept for the run.
+static bool run_is_alone(const cvh_context *c)
+{
+  if (c->run_alone < 0 || c->enqueued == 0) c->run_alone = live_contexts(c) <= 1 ? 1 : 0;
+  return c->run_alone != 0;
+}
+
 static double live_footprint(const cvh_context *c)
 {
   std::lock_guard<std::mutex> lk(g_live_mu);
@@ -801,10 +808,7 @@ static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
   // ~25 us each, while interleaved per-launch flows fill each other's gaps -- measured, eight images interleaved in chunks of 8 iterations
   // (tools/batch_probe.py, gpurun_out/r4s9): 2048^2 32.6 us per image-iteration resident vs 16.2 per launch (17.3 with chunks of 50);
   // 1024^2 22.3 vs 6.1 (10.6).  Decided when a run's first iteration is enqueued, kept for the run.
-  if (c->resident_opt < 0) {
-    if (c->run_alone < 0 || c->enqueued == 0) c->run_alone = live_contexts(c) <= 1 ? 1 : 0;
-    if (!c->run_alone) return false;
-  }
+  if (c->resident_opt < 0 && !run_is_alone(c)) return false;
   if (c->resident_cap < 0) {
     int coop = 0;
     c->resident_cap = 0;
@@ -1064,7 +1068,8 @@ extern "C" int cvh_debug_data_flow(int h, int w, int channels, int math_mode, in
 static int upload_strip_bounds(cvh_context *c, const Geometry &g)
 {
   const int cls = (((g.strip == 3 && c->wave_cls) || (g.strip == 2 && c->wave_cls == 2)) && c->wave_xcd) ? (c->num_cus >= 8 ? c->num_cus / 8 : 1) : 0;
-  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip + (c->state_bits == 32 ? 500000000 : 0), c->h};
+  const bool alone = run_is_alone(c);
+  const int key[4] = {g.tiles_y, g.strip_rows, c->wave_skew + 1000 * (cls ? c->wave_cskew + 1 : 0) + 10000000 * g.strip + (c->state_bits == 32 ? 500000000 : 0) + (alone ? 0 : 250000000), c->h};
   if (!memcmp(key, c->bounds_key, sizeof(key))) return CVH_OK;
   std::vector<int> b;
   // The skew pays for short strips only (one process, 2-pixel kernel: 4096^2, 46 rows: 61.1 -> 58.7 us; 6144^2, 102 rows: 140.9 ->
@@ -1077,6 +1082,9 @@ static int upload_strip_bounds(cvh_context *c, const Geometry &g)
   // priority scheme 2) us.  Any other "wave_cskew" applies as given.
   // (the FP32-state flavour of three channels, compute-bound, still prefers equal strips: 52.5 vs 54.6 us, gpurun_out/r4s19)
   if (c->C == 3 && c->wave_cskew == 500) cskew = c->state_bits == 32 ? 0 : 425;
+  // a batch: launches of several contexts interleave on the CUs, the staircase of ONE launch's dispatch rounds is not what ends a launch any more --
+  // equal strips (8 interleaved 4096^2 images, `bench.py --config C5`: 298.1 k against 293.2-293.4 k Mpixel-iterations/s, gpurun_out/r4s23)
+  if (!alone && c->wave_cskew == 500) cskew = 0;
   compute_strip_bounds(g.strip, c->h, g.tiles_x, g.tiles_y, g.strip_rows, g.nblocks, cls, cskew, c->wave_skew, b);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // launches already enqueued read the old table
   HIPCHK(c, hipMemcpy(c->d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
