@@ -54,6 +54,7 @@ struct cvh_context {
   int pm_kernel = -1;   // -1 auto (4 where the plane and the run qualify, else 3), 0 tile kernel, 1 wave kernel, 3 two time steps per launch, 4 resident plane
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = -1 /* auto: 1 channel 1, 3 channels 0 */, wave_imgv = 1, wave_depth = 4;
+  int res_prio = 1;     // option "res_prio": resident kernels, priority by quarters of a wave's band (csv_resident_kernel.hip)
   int near_switch = 1;  // option "near_switch": per-wave, per-group choice of the form of H_eps (csv_wave2_kernel.hip); 0 = far form + correction always
   double *d_dummy = nullptr;
   int wave_rev = 0, wave_xcd = 1;
@@ -433,6 +434,8 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     c->wave_sync = value < 0 ? -1 : (value != 0);
   } else if (!strcmp(key, "near_switch")) {
     c->near_switch = value != 0;
+  } else if (!strcmp(key, "res_prio")) {
+    c->res_prio = value != 0;
   } else if (!strcmp(key, "co_resident")) {
     c->co_resident = value != 0;
   } else if (!strcmp(key, "state")) {
@@ -887,6 +890,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   // with three channels the barrier costs more than the locality returns (4096^2 x 3, one context: 73.0-74.4 -> 71.9-73.2 us)
   a->wave_sync = c->wave_sync >= 0 ? c->wave_sync : (c->C == 3 ? 0 : 1);
   a->near_switch = c->near_switch;
+  a->res_prio = c->res_prio;
   a->wave_depth = c->wave_depth;
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;
@@ -1487,6 +1491,7 @@ static int pm_run_resident(cvh_context *c, const CvhPmArgs &base, const Resident
   { const int rc = ensure_resident_buffers(c); if (rc != CVH_OK) return rc; }
   CvhPmArgs a = base;
   a.tiles_x = rg.tc; a.tiles_y = rg.tr; a.res_band_rows = rg.band;
+  a.res_prio = c->res_prio;
   a.resident = c->d_resident;
   if (!c->d_pm_halo) {
     const size_t bytes = (size_t)2 * CVH_RESIDENT_MAX_TILES * cvh_pm_resident_halo_doubles() * sizeof(double);

@@ -358,11 +358,24 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
           acc[2] = __builtin_fma((double)(smp_keep[k] >> 8), db, acc[2]);
         }
       };
+      // Two waves share a SIMD and at equal priority the arbiter serves the OLDER one first: it is through its band after 7.3 us, the younger
+      // then runs alone -- a single wave hides no latency -- until 12 us (profiles/r03_C4/resident_timeline_2048.txt).  A wave lowers its priority
+      // with every quarter of its band (as the per-launch kernels do by quarters of their strips): whoever is AHEAD yields, the two leapfrog by
+      // groups of rows and finish together, two waves overlapping to the end.  (option "res_prio", default on)
+      auto quarter_prio = [&](int done, int of) {
+        if (!a.res_prio) return;
+        const int q = of >= 4 ? (4 * done) / of : done;      // quarters of the band behind this wave
+        if (q <= 0) __builtin_amdgcn_s_setprio(3);
+        else if (q == 1) __builtin_amdgcn_s_setprio(2);
+        else if (q == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      };
       auto march = [&](auto near_tag) {
         constexpr bool NEARFORM = decltype(near_tag)::value;
         if (NRT >= 4) {
 #pragma unroll
           for (int g = 0; g < NRT / 4; ++g) {
+            quarter_prio(4 * g, NRT);
 #pragma unroll
             for (int k = 0; k < 4; ++k) row(4 * g + k, k, near_tag);
             if (NEARFORM || (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
@@ -376,6 +389,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         } else {
           int rel = 0;
           for (; rel + 4 <= rb1 - rb0; rel += 4) {
+            quarter_prio(rel, rb1 - rb0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) row(rel + k, k, near_tag);
             if (NEARFORM || (near_mask[0] | near_mask[1] | near_mask[2] | near_mask[3]) != 0ull) {
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         }
       };
       if (near_band) march(std::true_type{}); else march(std::false_type{});
+      if (a.res_prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] = lane_valid ? acc[s] : 0.0;   // lanes beyond the image contribute nothing
     }

@@ -126,6 +126,7 @@ struct CvhStepArgs {
   double *res_halo;              // [2][tiles][6 * 128] border rows / columns of every tile, by iteration parity
   int res_steps, res_poll_cap;   // iterations in this launch; polls before a wait gives up
   int res_t0;                    // index of the launch's first iteration inside the run (= iterations enqueued before it)
+  int res_prio;                  // resident kernels: a wave lowers its priority with every quarter of its band (the two waves of a SIMD finish together)
   int res_band_rows;             // rows per wave when every tile has 8 x that many rows (2, 4, 8, 16: straight-line march), else 0
 };
 
@@ -158,6 +159,7 @@ struct CvhPmArgs {
   unsigned res_serial;           // tag of this launch (entries left by earlier launches never match)
   int res_steps;
   int res_band_rows;             // rows per wave: 2, 4, 8 or 16 (tiles of 8 x that many rows)
+  int res_prio;                  // a wave lowers its priority with every quarter of its band (csv_resident_kernel.hip, quarter_prio)
   int res_poll_cap;              // polls before a wait gives up
   unsigned long long *dbg_times; // diagnostic (option "debug_times", tools/pm_resident_timeline.py): 12 stamps per workgroup, or null
   CvhLaunchNote *note;   // host only: describe the launch instead of issuing it (CVH_LAUNCH)

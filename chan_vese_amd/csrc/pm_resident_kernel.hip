@@ -296,6 +296,15 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         const int i = rb0 + k;
+        // (the two waves of a SIMD: whoever is ahead yields -- csv_resident_kernel.hip, quarter_prio: the older wave was through its band
+        // after 4.6 us of a step's 6.6, the younger then ran alone)
+        if (a.res_prio && NR >= 4 && k % (NR / 4) == 0) {
+          const int q = k / (NR / 4);
+          if (q == 0) __builtin_amdgcn_s_setprio(3);
+          else if (q == 1) __builtin_amdgcn_s_setprio(2);
+          else if (q == 2) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
         const Row xpp = xq;
         if (k + 1 < NR) xq = load_row(i + 3);
         const double gw_e = pw[k], ge_e = pe[k];
