@@ -7,6 +7,8 @@ from chan_vese_amd import capi, synth
 n = int(os.environ.get("N", "2048"))
 ctx = capi.Context(n, n, 1)
 ctx.set_option("pm_kernel", 4); ctx.set_option("math_mode", int(os.environ.get("MATH", "2")))
+for kv in sys.argv[1:]:          # further options as key=value, e.g. res_prio=0
+    k, v = kv.split("="); ctx.set_option(k, int(v))
 img = synth.disk(n, 200, 50, noise=40, seed=1)
 ctx.set_image([img]); ctx.perona_malik(30.0, 0.25, 50.0)          # clocks up
 info = ctx.launch_info(1); nt = int(info["grid"])
