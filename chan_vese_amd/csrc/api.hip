@@ -55,6 +55,7 @@ struct cvh_context {
   int pm_strip_rows = 0;
   int wave_minw = 5, wave_lds_cap = 0, wave_prio = 1, wave_sync = -1 /* auto: 1 channel 1, 3 channels 0 */, wave_imgv = 1, wave_depth = 4;
   int res_prio = 1;     // option "res_prio": resident kernels, priority by quarters of a wave's band (csv_resident_kernel.hip)
+  int res_go_share = 5;  // option "res_go_share": log2 of the tiles of an XCD that share one release line of the resident kernel (0: a line per tile, 5: a line per XCD, 6: one line)
   int near_switch = 1;  // option "near_switch": per-wave, per-group choice of the form of H_eps (csv_wave2_kernel.hip); 0 = far form + correction always
   double *d_dummy = nullptr;
   int wave_rev = 0, wave_xcd = 1;
@@ -395,7 +396,7 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     if (c->d_dbg) { HIPCHK(c, hipFree(c->d_dbg)); c->d_dbg = nullptr; c->dbg_words = 0; }
     if (value > 0) {
       c->dbg_words = (size_t)c->partial_rows * 20 + 16;
-      if (c->dbg_words < (size_t)CVH_RESIDENT_MAX_TILES * 12) c->dbg_words = (size_t)CVH_RESIDENT_MAX_TILES * 12;   // resident kernel: 12 words per tile
+      if (c->dbg_words < (size_t)CVH_RESIDENT_MAX_TILES * 12 + 64) c->dbg_words = (size_t)CVH_RESIDENT_MAX_TILES * 12 + 64;   // resident kernel: 12 words per tile + 64 of the master
       HIPCHK(c, hipMalloc((void **)&c->d_dbg, c->dbg_words * 8));
       HIPCHK(c, hipMemset(c->d_dbg, 0, c->dbg_words * 8));
     }
@@ -436,6 +437,9 @@ extern "C" int cvh_set_option(cvh_context *c, const char *key, long value)
     c->near_switch = value != 0;
   } else if (!strcmp(key, "res_prio")) {
     c->res_prio = value != 0;
+  } else if (!strcmp(key, "res_go_share")) {
+    if (value < 0 || value > 6) return fail(c, CVH_ERR_ARG, "res_go_share must be 0 .. 6");
+    c->res_go_share = (int)value;
   } else if (!strcmp(key, "co_resident")) {
     c->co_resident = value != 0;
   } else if (!strcmp(key, "state")) {
@@ -891,6 +895,7 @@ static void fill_args(const cvh_context *c, CvhStepArgs *a, int in_buf, int step
   a->wave_sync = c->wave_sync >= 0 ? c->wave_sync : (c->C == 3 ? 0 : 1);
   a->near_switch = c->near_switch;
   a->res_prio = c->res_prio;
+  a->res_go_shift = c->res_go_share;
   a->wave_depth = c->wave_depth;
   a->wave_imgv = c->wave_imgv;
   a->dummy = c->d_dummy;
@@ -1189,6 +1194,8 @@ static int ensure_resident_buffers(cvh_context *c)
 {
   if (c->d_resident) return CVH_OK;
   const int halo = cvh_resident_halo_doubles();
+  // (fine-grained and uncached device memory -- hipExtMallocWithFlags -- for these lines and buffers were tried: no difference,
+  // profiles/r04_C4/resident_memory_kinds.txt)
   HIPCHK(c, hipMalloc((void **)&c->d_resident, sizeof(CvhResident)));
   HIPCHK(c, hipMalloc((void **)&c->d_res_halo, (size_t)2 * CVH_RESIDENT_MAX_TILES * halo * sizeof(double)));
   HIPCHK(c, hipHostMalloc((void **)&c->h_resident, 64, hipHostMallocDefault));

@@ -60,7 +60,8 @@ struct ResSmem {
   static constexpr int doubles = off_flag + 4 + (RT_WAVES + 1) / 2 + 1 + RT_WAVES / 2;   // 3 broadcast doubles, 12 ints, the master's RT_WAVES ints
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
-static_assert(32 * RT_WAVES >= CVH_RESIDENT_MAX_TILES, "the master's waves watch 32 arrival lines each");
+static_assert(64 * (RT_WAVES / 2) >= CVH_RESIDENT_MAX_TILES, "the master's four polling waves watch 64 arrival lines each");
+static_assert(RT_WAVES * ResSmem::NS >= 3 * RT_WAVES + 3 * (RT_WAVES / 2), "sred holds the tiles' 8 x 3 partial sums and the master's 4 x 3");
 static_assert(ResSmem::bytes <= 160 * 1024, "the tile, its halo ring and the tables must fit one CU's LDS");
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -68,30 +69,6 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Sum over the workgroup's 8 waves in a fixed order; every thread returns the total of sum `s` it asked for (s < NS).
-template <int NS>
-__device__ __forceinline__ void block_reduce8(double (&acc)[NS], double *sred /*[8*NS]*/, double (&total)[NS])
-{
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double v[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) v[s] = wave_sum(acc[s]);
-  __syncthreads();
-  if (lane == 0) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) sred[wave * NS + s] = v[s];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    double t = sred[s];
-#pragma unroll
-    for (int wv = 1; wv < RT_WAVES; ++wv) t += sred[wv * NS + s];   // fixed order
-    total[s] = t;
-  }
-  __syncthreads();
-}
 
 // 16-byte agent-scope (sc1) accesses to the synchronisation lines: one lane, one transaction.
 typedef unsigned int u32x4r_t __attribute__((ext_vector_type(4)));
@@ -111,17 +88,34 @@ __device__ __forceinline__ void st_line16_u64(void *base, unsigned byte_off, uns
 __device__ __forceinline__ long long line16_i64(u32x4r_t v) { return (long long)(((unsigned long long)v.w << 32) | v.z); }
 __device__ __forceinline__ double line16_f64(u32x4r_t v) { return __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z)); }
 
+// Release lines are shared: workgroups are dealt to the 8 XCDs round-robin, and 2^shift tiles of one XCD read the same line (shift 0: a
+// line per tile).  The master's release is then 2 * 256 / 2^shift sixteen-byte stores instead of 512 -- one wave needs 1.2 us to drain 512
+// of them (the last tile saw its release 1.3 us after the first store was issued, profiles/r04_C4/resident_timeline_2048_master1.txt).
+__device__ __forceinline__ unsigned go_line(int tile, int shift) { return shift >= 6 ? 0u : (unsigned)((tile & 7) + 8 * ((tile >> 3) >> shift)); }   // (6: one line for all)
+__device__ __forceinline__ int go_lines(int ntiles, int shift) { return shift >= 6 ? 1 : 8 * ((((ntiles - 1) >> 3) >> shift) + 1); }
+
 // Thread 0 polls this workgroup's release line until both halves carry generation >= `gen` (bounded); the workgroup meets at a
 // barrier.  Returns the leave bit (or -1: gave up) and the region means the line carries.
-__device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int gen, const CvhStepArgs &a, double *s_bc /*[4]*/, double &c1, double &c2)
+// A workgroup barrier that orders LDS only: __syncthreads() also waits for every global store the wave has in flight, and on the way
+// from one iteration into the next the master's wave 0 has its bookkeeping stores under way (some of them to pinned HOST memory: 1.7 us
+// until the last one is acknowledged -- profiles/r04_C4/resident_timeline_2048_master1.txt, first collection).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// (`own`: the master workgroup wrote this very release itself -- thread 0 passes what it wrote, own.gen = its generation, and no line is polled)
+struct OwnRelease { int gen, leave; double c1, c2; };
+__device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int gen, const CvhStepArgs &a, double *s_bc /*[4]*/, double &c1, double &c2,
+                                          const OwnRelease &own)
 {
   if (threadIdx.x == 0) {
     int res = -1;
     double m1 = 0.0, m2 = 0.0;
+    if (own.gen == gen) { res = own.leave; m1 = own.c1; m2 = own.c2; }
+    else
     // (one poll in flight: two or four in flight sample the line more often but cost 0.5 / 0.7 us per iteration at 2048^2 -- the
     // polls of 256 workgroups compete with the arrivals and the release for the same fabric)
     for (int i = 0; i < a.res_poll_cap; ++i) {
-      const u32x4r_t ga = ld_line16(rs->go, (unsigned)bid * 64u), gb = ld_line16(rs->go, (unsigned)bid * 64u + 16u);
+      const unsigned line = go_line(bid, a.res_go_shift) * 64u;
+      const u32x4r_t ga = ld_line16(rs->go, line), gb = ld_line16(rs->go, line + 16u);
       if (ga.x == gb.x && ga.x >= (unsigned)gen && ga.x != 0xffffffffu) { res = (int)(ga.y & 1u); m1 = line16_f64(ga); m2 = line16_f64(gb); break; }
       if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
       if (i >= 64) __builtin_amdgcn_s_sleep(16); else if (i >= 2) __builtin_amdgcn_s_sleep(kReleaseSleep);
@@ -129,10 +123,10 @@ __device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int ge
     if (res < 0) st_agent(const_cast<int *>(&rs->error), 1);
     s_bc[0] = (double)res; s_bc[1] = m1; s_bc[2] = m2;
   }
-  __syncthreads();
+  lds_barrier();
   const int res = (int)s_bc[0];
   c1 = s_bc[1]; c2 = s_bc[2];
-  __syncthreads();
+  lds_barrier();
   return res;
 }
 
@@ -159,6 +153,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < RT_WAVES) s_mflag[tid] = 0;
+  if (tid == 0) s_flag[9] = 0;             // master workgroup: waves whose border stores are acknowledged, counted over the launch
   const int h = a.h, w = a.w;
   CvhResident *const rs = a.resident;
   // sticky stop flag of an EARLIER launch (src/main.cpp:1000): read at agent scope -- every workgroup must see the same value, and a
@@ -236,12 +231,38 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   int executed = 0;
   bool gave_up = false;
   const int nit = a.res_steps;
+  int it = 0;
+  // The master's books of one iteration (thread 0 of workgroup 0): trace row, state block and -- when the launch ends or the stop rule
+  // fired -- the two words the host polls in pinned memory.  (Inside a launch the host does not need them: it runs at most four launches
+  // ahead of the count the LAST word of a launch reports; a store to host memory is acknowledged after 1.5 us, and a wave cannot wait for
+  // anything else of its own without waiting for that.)
+  auto book = [&](double m1, double m2, double nrm, int stop_now, bool last) {
+    if (tid != 0) return;
+    CvhState *st = a.st;
+    const int t = t_first + it;
+    if (a.trace && t < a.trace_cap) { a.trace[(size_t)t * 3] = m1; a.trace[(size_t)t * 3 + 1] = m2; a.trace[(size_t)t * 3 + 2] = nrm; }
+    st->norm = nrm;
+    st->steps_done = t + 1;
+    st->pending = 0;
+    if (stop_now) st->stopped = 1;
+    if (a.host_status && last) {
+      __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
+  // (master workgroup: the release it wrote itself, handed from thread 0 to the workgroup without a poll)
+  OwnRelease own = {-1, 0, 0.0, 0.0};
+  bool book_pending = false;   // (wave 0 of the master) iteration `it` is released but not yet booked
+  double book_nrm = 0.0;
+  bool have_go = false;      // (workgroup-uniform) the release into the next iteration was handed over inside the workgroup
+  int go_known = -1;
   if (bid == 0 && tid == 0) { rs->pad[0] = (unsigned)t_first; rs->pad[1] = (unsigned)nit; rs->pad[2] = (unsigned)a.st->steps_done; }   // (diagnostic record of the launch)
-  for (int it = 0; it < nit; ++it) {
+  for (it = 0; it < nit; ++it) {
     const int phase = (a.chain_phase + it) & 3;
     // ---- the release behind iteration it - 1: leave bit and the region means of u(it); the halos were fetched while waiting
     if (it > 0) {
-      const int go = wg_wait_go(rs, bid, it, a, s_bc, c1, c2);
+      const int go = have_go ? go_known : wg_wait_go(rs, bid, it, a, s_bc, c1, c2, own);   // (have_go: the master workgroup, short way)
+      have_go = false;
       if (go < 0) { gave_up = true; break; }
       if (go & 1) break;
     }
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     const double2_t ubot = *reinterpret_cast<const double2_t *>(S(rb1, ca));
     double uw = *S(rb0, ca - 1), ue = *S(rb0, ca + 2);
     const double2_t u1st = *reinterpret_cast<const double2_t *>(S(rb0 + 1 < rb1 ? rb0 + 1 : rb0, ca));   // row rb0 + 1 (own band, if it has one)
-    __syncthreads();
+    lds_barrier();                                             // (LDS only: the master's bookkeeping stores may still be in flight)
     stamp(it, kStampIt, 1);                                    // table in LDS, band borders in registers
 
     double acc[NS];
@@ -372,7 +393,19 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       };
       auto march = [&](auto near_tag) {
         constexpr bool NEARFORM = decltype(near_tag)::value;
-        if (NRT >= 4) {
+        if (NRT >= 16 && NEARFORM) {
+          // (the near copy of a 16-row band is a LOOP over its four groups: unrolled, the table forms of sixteen rows in flight took the
+          // kernel to 256 VGPRs and 141 spilled registers, and values that live across the march were reloaded from scratch on the
+          // far path as well)
+#pragma unroll 1
+          for (int g = 0; g < NRT / 4; ++g) {
+            quarter_prio(4 * g, NRT);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) row(4 * g + k, k, near_tag);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) correct(k, near_tag);
+          }
+        } else if (NRT >= 4) {
 #pragma unroll
           for (int g = 0; g < NRT / 4; ++g) {
             quarter_prio(4 * g, NRT);
@@ -406,170 +439,229 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       for (int s = 0; s < NS; ++s) acc[s] = lane_valid ? acc[s] : 0.0;   // lanes beyond the image contribute nothing
     }
     stamp(it, kStampIt, 2);                                    // (thread 0's wave) march done
-    double total[NS];
-    block_reduce8<NS>(acc, sred, total);    // (its barriers also order the tile writes before the border reads below)
-    stamp(it, kStampIt, 3);                                    // all waves done, sums reduced
+    if (a.dbg_times && it == kStampIt && lane == 0 && (bid == 0 || bid == 100 || bid == 255))   // diagnostic: every wave of three tiles
+      a.dbg_times[(size_t)CVH_RESIDENT_MAX_TILES * 12 + 16 + (bid == 0 ? 0 : bid == 100 ? 8 : 16) + wave] = __builtin_amdgcn_s_memrealtime();
+    // ---- the tile's sums and its arrival.  One channel, H' sums: of the NS sums only [0] sum H', [2] sum I H' and [4] sum u_diff^2 are
+    // carried.  Every wave reduces its three (DPP), lane 0 leaves them in LDS, ONE barrier (it also orders the tile writes before the border
+    // reads below), and the three threads that store the arrival add the eight partials in a fixed order -- nobody else needs the totals.
+    // (sred[0 .. 24): these partials; sred[24 .. 36): the master's, below)
+    {
+      const double v0 = wave_sum(acc[0]), v2 = wave_sum(acc[2]), v4 = wave_sum(acc[4]);
+      if (lane == 0) { sred[wave * 3] = v4; sred[wave * 3 + 1] = v0; sred[wave * 3 + 2] = v2; }
+    }
+    __syncthreads();
+    stamp(it, kStampIt, 3);                                    // all waves done, sums in LDS
     executed = it + 1;
     const unsigned gen = (unsigned)(it + 1);
-
-    // ---- arrive: three 16-byte lines {generation, payload}: sum u_diff^2, and the fixed-point sums the next iteration's means come from
-    // (distinct addresses: 256 arrivals on one counter serialise for 6 us).  The arrival does not wait for the border stores below: the
-    // master needs the sums only, the neighbours get their own signal.
+    // three 16-byte lines {generation, payload}: sum u_diff^2, and the fixed-point sums the next iteration's means come from (distinct
+    // addresses: 256 arrivals on one counter serialise for 6 us).  The arrival does not wait for the border stores below: the master needs
+    // the sums only, the neighbours get their own signal.
     if (tid < 3) {
-      const unsigned long long payload = tid == 0 ? (unsigned long long)__double_as_longlong(total[4])
-                                       : tid == 1 ? (unsigned long long)__double2ll_rn(total[0] * a.chain_scale[0])
-                                                  : (unsigned long long)__double2ll_rn(total[2] * a.chain_scale[1]);
+      double t = sred[tid];
+#pragma unroll
+      for (int wv = 1; wv < RT_WAVES; ++wv) t += sred[wv * 3 + tid];   // fixed order
+      const unsigned long long payload = tid == 0 ? (unsigned long long)__double_as_longlong(t)
+                                       : (unsigned long long)__double2ll_rn(t * a.chain_scale[tid - 1]);
       st_line16_u64(rs->flag, (unsigned)bid * 64u + 16u * (unsigned)tid, gen, 0u, payload);
     }
-    // ---- the tile's border for the neighbours, then the border signal
-    {
-      double *const hb = halo_mine[it & 1];
-      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
-        const int piece = q / RT_W, k = q % RT_W;
-        double v;
-        if (piece < 2) v = *S(TH - 2 + piece, k);                    // bottom two rows   (TH >= 2: host)
-        else if (piece == 2) v = *S(0, k);                           // top row
-        else if (piece < 5) v = *S(k < TH ? k : 0, TWv - 5 + piece);  // right two columns: TWv - 2, TWv - 1
-        else v = *S(k < TH ? k : 0, 0);                              // left column
-        st_agent_f64(hb + q, v);
+    // ---- what crosses to the neighbours: the tile's border (6 x 128 doubles, agent-scope stores) and, once those are acknowledged, the
+    // border signal; then the neighbours' borders of u(it + 1) -- they exist as soon as the up-to-four neighbours have stored THEIR signal --
+    // go into the halo ring while the barrier completes; at the image's border: BORDER_REPLICATE from the tile's own edge (src/main.cpp:351-354)
+    double *const hb = halo_mine[it & 1];
+    auto store_border = [&](int q) {
+      const int piece = q / RT_W, k = q % RT_W;
+      double v;
+      if (piece < 2) v = *S(TH - 2 + piece, k);                    // bottom two rows   (TH >= 2: host)
+      else if (piece == 2) v = *S(0, k);                           // top row
+      else if (piece < 5) v = *S(k < TH ? k : 0, TWv - 5 + piece);  // right two columns: TWv - 2, TWv - 1
+      else v = *S(k < TH ? k : 0, 0);                              // left column
+      st_agent_f64(hb + q, v);
+    };
+    const bool want_borders = it + 1 < nit;
+    const int nb_lane = lane == 0 ? (ty > 0 ? bid - tc : -1) : lane == 1 ? (ty < tr - 1 ? bid + tc : -1) : lane == 2 ? (tx > 0 ? bid - 1 : -1)
+                        : lane == 3 ? (tx < tc - 1 ? bid + 1 : -1) : -1;          // lanes 0-3 of a polling wave watch one neighbour each
+    auto tagged = [&](const u32x4r_t &f) -> bool { return f.x >= gen && f.x != 0xffffffffu; };
+    // (a wave-wide bounded wait for the lanes' neighbours)
+    auto neighbours_arrived = [&]() -> int {
+      bool sat = nb_lane < 0;
+      for (int i = 0; i < a.res_poll_cap; ++i) {
+        if (!sat) sat = tagged(ld_line16(rs->hflag, (unsigned)(nb_lane < 0 ? 0 : nb_lane) * 64u));
+        if (__builtin_amdgcn_ballot_w64(!sat) == 0ull) return 1;
+        if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
       }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stamp(it, kStampIt, 4);                                    // borders have reached memory
-    if (tid == 0) st_line16_u64(rs->hflag, (unsigned)bid * 64u, gen, 0u, 0ull);
+      return 0;
+    };
+    const double *const hbn = a.res_halo + (size_t)(it & 1) * ntiles * RT_HALO;
+    // element q of the 6 x 128 border: its value (a neighbour's store, or the tile's own edge) into the halo cell it belongs to
+    auto fetch = [&](int q) {
+      const int piece = q / RT_W, k = q % RT_W;
+      double *dst;
+      double v;
+      if (piece < 2) {            // top halo rows -2, -1 <- the tile above's bottom two rows
+        dst = S(piece - 2, k);
+        v = ty > 0 ? ld_agent_f64(hbn + (size_t)(bid - tc) * RT_HALO + piece * RT_W + k) : *S(0, k);
+      } else if (piece == 2) {    // bottom halo row TH <- the tile below's top row
+        dst = S(TH, k);
+        v = ty < tr - 1 ? ld_agent_f64(hbn + (size_t)(bid + tc) * RT_HALO + 2 * RT_W + k) : *S(TH - 1, k);
+      } else if (piece < 5) {     // left halo columns -2, -1 <- the left tile's right two columns
+        dst = k < TH ? S(k, piece - 5) : nullptr;
+        v = tx > 0 ? ld_agent_f64(hbn + (size_t)(bid - 1) * RT_HALO + piece * RT_W + k) : *S(k < TH ? k : 0, 0);
+      } else {                    // right halo column TWv <- the right tile's left column
+        dst = k < TH ? S(k, TWv) : nullptr;
+        v = tx < tc - 1 ? ld_agent_f64(hbn + (size_t)(bid + 1) * RT_HALO + 5 * RT_W + k) : *S(k < TH ? k : 0, TWv - 1);
+      }
+      if (dst) *dst = v;
+    };
 
-    // ---- workgroup 0 is the barrier's master.  Its eight waves watch 32 arrival lines each (lanes 0-31: the norm and sum-H' pieces,
-    // lanes 32-63: the sum-I H' piece) WITHOUT workgroup barriers: a wave whose share is complete leaves its partial sums and the
-    // generation in LDS and goes on; wave 0 collects the eight, books the iteration and releases everybody.  (Single-wave code is
-    // latency-bound -- 8 cycles an instruction: everything here is the critical path of 255 waiting workgroups.)
-    if (bid == 0) {
-      const int b = wave * 32 + (lane & 31);                    // (host: ntiles <= 32 * RT_WAVES)
-      const bool have = b < ntiles;
-      bool done = false;
-      u32x4r_t fa = {0u, 0u, 0u, 0u}, fb = {0u, 0u, 0u, 0u};
-      // (one poll in flight: two in flight, half a round trip apart, sample a line twice as often and are SLOWER -- 2048^2 14.60 -> 15.04 us,
-      // 1024^2 7.89 -> 8.19: reads of a line that is being written get in the way of the write)
-      for (int round = 0; round < a.res_poll_cap; ++round) {
-        if (have) {
-          fa = ld_line16(rs->flag, (unsigned)b * 64u + (lane < 32 ? 0u : 32u));
-          if (lane < 32) fb = ld_line16(rs->flag, (unsigned)b * 64u + 16u);
+    if (bid != 0) {
+      // ---- an ordinary tile: border, border signal, the neighbours' borders; the release is polled at the top of the next iteration
+      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) store_border(q);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      stamp(it, kStampIt, 4);                                    // borders have reached memory
+      if (tid == 0) st_line16_u64(rs->hflag, (unsigned)bid * 64u, gen, 0u, 0ull);
+      if (want_borders) {
+        if (tid < 64) {
+          const int ok = neighbours_arrived();
+          if (lane == 0) { if (!ok) st_agent(&rs->error, 1); s_flag[0] = ok; }
         }
-        const bool ok = !have || (fa.x >= gen && fa.x != 0xffffffffu && (lane >= 32 || (fb.x >= gen && fb.x != 0xffffffffu)));
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { done = true; break; }
-        if ((round & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-        __builtin_amdgcn_s_sleep(kMasterSleep);
+        __syncthreads();
+        const int okn = s_flag[0];
+        __syncthreads();
+        if (!okn) { gave_up = true; break; }
+        for (int q = tid; q < 6 * RT_W; q += RT_THREADS) fetch(q);
+        // (the barrier at the top of the next iteration orders these LDS writes before their readers)
       }
-      if (done) {
-        const double ws = wave_sum((have && lane < 32) ? line16_f64(fa) : 0.0);                       // fixed order: lane = tile
-        const long long r = row16_sum_i64(!have ? 0ll : lane < 32 ? line16_i64(fb) : line16_i64(fa));
-        const long long w0 = read_lane_i64(r, 0) + read_lane_i64(r, 16), w1 = read_lane_i64(r, 32) + read_lane_i64(r, 48);
-        if (lane == 0) {
-          sred[wave * NS] = ws;
-          reinterpret_cast<long long *>(sred)[wave * NS + 1] = w0;
-          reinterpret_cast<long long *>(sred)[wave * NS + 2] = w1;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __hip_atomic_store(&s_mflag[wave], (int)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      // ---- workgroup 0 is the barrier's MASTER, and a tile like any other -- among the last to arrive as often as any other, so nothing of
+      // its own may stand between its arrival and its first look at the arrival lines.  Its waves split the work (no workgroup barrier
+      // until the release is out):
+      //   waves 0-3 POLL: 64 arrival lines each, lane = tile, three 16-byte pieces per line; a wave whose share is complete leaves its
+      //     partial sums and the generation in LDS; wave 0 collects the four, books the iteration and releases everybody.  These waves
+      //     have no store in flight: memory operations of a wave return in order, and polls issued behind the border stores came back
+      //     after 1.4 us instead of 0.8 (profiles/r04_C4/resident_timeline_2048_master_waves.txt);
+      //   waves 4-7 WORK: the tile's border stores, the border signal (the last of the four whose stores are acknowledged), the wait for
+      //     the tile's own neighbours and the fetch of their borders -- finished long before the release is.
+      // (Single-wave code is latency-bound -- 8 cycles an instruction: everything wave 0 does is the critical path of 255 waiting
+      // workgroups.)  Round-4 history of this block: DESIGN.md 4.1b.
+      constexpr int kPollWaves = RT_WAVES / 2, kWorkThreads = RT_THREADS - 64 * kPollWaves;
+      static_assert(64 * kPollWaves >= CVH_RESIDENT_MAX_TILES, "the master's polling waves watch 64 arrival lines each");
+      int ok_w = 1;                  // (wave-uniform) this wave's errand went well
+      if (wave >= kPollWaves) {
+        for (int q = tid - 64 * kPollWaves; q < 6 * RT_W; q += kWorkThreads) store_border(q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && __hip_atomic_fetch_add(&s_flag[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == (RT_WAVES - kPollWaves) * (int)gen) {
+          if (a.dbg_times && it == kStampIt) a.dbg_times[(size_t)bid * 12 + 4] = __builtin_amdgcn_s_memrealtime();
+          st_line16_u64(rs->hflag, (unsigned)bid * 64u, gen, 0u, 0ull);
         }
-      } else if (lane == 0) st_agent(&rs->error, 1);
-      if (wave == 0 && done) {
-        bool all = false;
+        if (want_borders) {
+          ok_w = neighbours_arrived();
+          if (ok_w) for (int q = tid - 64 * kPollWaves; q < 6 * RT_W; q += kWorkThreads) fetch(q);
+        }
+        if (lane == 0 && !ok_w) st_agent(&rs->error, 1);
+      } else {
+        const int b = wave * 64 + lane;
+        const bool have = b < ntiles;
+        bool done = false;
+        u32x4r_t fa = {0u, 0u, 0u, 0u}, fb = {0u, 0u, 0u, 0u}, fc = {0u, 0u, 0u, 0u};
+        // (one poll in flight: two in flight, half a round trip apart, sample a line twice as often and are SLOWER -- 2048^2 14.60 -> 15.04 us,
+        // 1024^2 7.89 -> 8.19: reads of a line that is being written get in the way of the write)
+        int rounds = 0;
+        bool ok = !have;             // (per lane, sticky: a line that has arrived is not read again -- the last rounds poll the stragglers only)
         for (int round = 0; round < a.res_poll_cap; ++round) {
-          const int f = lane < RT_WAVES ? __hip_atomic_load(&s_mflag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (int)gen;
-          if (__builtin_amdgcn_ballot_w64(f != (int)gen) == 0ull) { all = true; break; }
-          if ((round & 63) == 63 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+          if (!ok) {
+            fa = ld_line16(rs->flag, (unsigned)b * 64u);
+            fb = ld_line16(rs->flag, (unsigned)b * 64u + 16u);
+            fc = ld_line16(rs->flag, (unsigned)b * 64u + 32u);
+          }
+          ok = !have || (tagged(fa) && tagged(fb) && tagged(fc));
+          rounds = round + 1;
+          if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { done = true; break; }
+          if ((round & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+          __builtin_amdgcn_s_sleep(kMasterSleep);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (all) {
-          if (a.dbg_times && it == kStampIt && tid == 0) a.dbg_times[5] = __builtin_amdgcn_s_memrealtime();   // master: everybody has arrived
-          // iteration `it` is complete everywhere: norm (fixed order), stop rule (src/main.cpp:993-1000), region means of u(it + 1) from
-          // the integer totals
-          const double *vred = sred;                               // (plain LDS reads: the acquire fence above orders them)
-          const long long *vredq = reinterpret_cast<const long long *>(sred);
-          double s4 = vred[0];
-          long long q0 = vredq[1], q1 = vredq[2];
+        if (a.dbg_times && it == kStampIt && lane == 0) {   // diagnostic: when this wave's share was complete, after how many rounds
+          a.dbg_times[(size_t)CVH_RESIDENT_MAX_TILES * 12 + wave] = __builtin_amdgcn_s_memrealtime();
+          a.dbg_times[(size_t)CVH_RESIDENT_MAX_TILES * 12 + 8 + wave] = (unsigned long long)rounds;
+        }
+        if (done) {
+          const double ws = wave_sum(have ? line16_f64(fa) : 0.0);                       // fixed order: lane = tile
+          const long long r0s = row16_sum_i64(have ? line16_i64(fb) : 0ll), r1s = row16_sum_i64(have ? line16_i64(fc) : 0ll);
+          const long long w0 = (read_lane_i64(r0s, 0) + read_lane_i64(r0s, 16)) + (read_lane_i64(r0s, 32) + read_lane_i64(r0s, 48));
+          const long long w1 = (read_lane_i64(r1s, 0) + read_lane_i64(r1s, 16)) + (read_lane_i64(r1s, 32) + read_lane_i64(r1s, 48));
+          if (lane == 0) {
+            sred[24 + wave * 3] = ws;
+            reinterpret_cast<long long *>(sred)[24 + wave * 3 + 1] = w0;
+            reinterpret_cast<long long *>(sred)[24 + wave * 3 + 2] = w1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&s_mflag[wave], (int)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        } else { ok_w = 0; if (lane == 0) st_agent(&rs->error, 1); }
+        if (wave == 0 && done) {
+          bool all = false;
+          for (int round = 0; round < a.res_poll_cap; ++round) {
+            const int f = lane < kPollWaves ? __hip_atomic_load(&s_mflag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (int)gen;
+            if (__builtin_amdgcn_ballot_w64(f != (int)gen) == 0ull) { all = true; break; }
+            if ((round & 63) == 63 && ld_agent((const unsigned *)&rs->error) != 0u) break;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (all) {
+            if (a.dbg_times && it == kStampIt && tid == 0) a.dbg_times[5] = __builtin_amdgcn_s_memrealtime();   // master: everybody has arrived
+            // iteration `it` is complete everywhere: norm (fixed order), stop rule (src/main.cpp:993-1000), region means of u(it + 1) from
+            // the integer totals
+            const double *vred = sred + 24;                          // (plain LDS reads: the acquire fence above orders them)
+            const long long *vredq = reinterpret_cast<const long long *>(sred + 24);
+            double s4 = vred[0];
+            long long q0 = vredq[1], q1 = vredq[2];
 #pragma unroll
-          for (int wv = 1; wv < RT_WAVES; ++wv) { s4 += vred[wv * NS]; q0 += vredq[wv * NS + 1]; q1 += vredq[wv * NS + 2]; }   // fixed order
-          const double nrm = sqrt(s4);
-          const int stop_now = nrm <= a.stop_cond;          // :1000, after the update
-          // chain_means' formula (chain_device.h) on the totals
-          const double sh = __builtin_fma((double)q0, a.chain_inv[0], 0.5 * a.npix);
-          const double sih = __builtin_fma((double)q1, a.chain_inv[1], 0.5 * a.sum_img[0]);
-          const double n1 = sih / sh, n2 = (a.sum_img[0] - sih) / (a.npix - sh);
-          const unsigned leave = (stop_now || it + 1 >= nit) ? 1u : 0u;
-          stamp(it, kStampIt, 6);                                  // master: norm and means known
-          for (int i = lane; i < ntiles; i += 64) {
-            st_line16(rs->go, (unsigned)i * 64u, gen, leave, n1);
-            st_line16(rs->go, (unsigned)i * 64u + 16u, gen, leave, n2);
-          }
-          stamp(it, kStampIt, 7);                                  // master: release issued
-          // everything else the master books comes AFTER the release (off the critical path of the other workgroups).
-          // The last iteration of the launch leaves the sums where the per-launch path expects them: set p0 + executed filled (one
-          // shard per sum), the set behind it clear
-          if (leave) {
-            __hip_atomic_store(&a.chain->v[(phase + 1) & 3][lane], lane == 0 ? q0 : lane == 32 ? q1 : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.chain->v[(phase + 2) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (tid == 0) {
-            CvhState *st = a.st;
-            const int t = t_first + it;
-            if (a.trace && t < a.trace_cap) { a.trace[(size_t)t * 3] = c1; a.trace[(size_t)t * 3 + 1] = c2; a.trace[(size_t)t * 3 + 2] = nrm; }
-            st->norm = nrm;
-            st->steps_done = t + 1;
-            st->pending = 0;
-            if (stop_now) st->stopped = 1;
-            if (a.host_status) {
-              __hip_atomic_store(&a.host_status[1], stop_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              __hip_atomic_store(&a.host_status[0], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int wv = 1; wv < kPollWaves; ++wv) { s4 += vred[wv * 3]; q0 += vredq[wv * 3 + 1]; q1 += vredq[wv * 3 + 2]; }   // fixed order
+            const double nrm = sqrt(s4);
+            const int stop_now = nrm <= a.stop_cond;          // :1000, after the update
+            // chain_means' formula (chain_device.h) on the totals
+            const double sh = __builtin_fma((double)q0, a.chain_inv[0], 0.5 * a.npix);
+            const double sih = __builtin_fma((double)q1, a.chain_inv[1], 0.5 * a.sum_img[0]);
+            // (both quotients through one division sequence in lanes 0 / 1 was tried: norm + means 0.28 -> 0.50 us -- the two sequences overlap as they are)
+            const double n1 = sih / sh, n2 = (a.sum_img[0] - sih) / (a.npix - sh);
+            const unsigned leave = (stop_now || it + 1 >= nit) ? 1u : 0u;
+            stamp(it, kStampIt, 6);                                  // master: norm and means known
+            for (int i = lane, nl = go_lines(ntiles, a.res_go_shift); i < nl; i += 64) {
+              st_line16(rs->go, (unsigned)i * 64u, gen, leave, n1);
+              st_line16(rs->go, (unsigned)i * 64u + 16u, gen, leave, n2);
             }
-          }
-        } else if (lane == 0) st_agent(&rs->error, 1);
-      }
-      // (a master that gave up has raised the error word and released nobody: every wait below and in the other workgroups sees the
-      // word and leaves)
-    }
-
-    // ---- while the barrier completes: the neighbours' borders of u(it + 1) (they exist as soon as the up-to-four neighbours have
-    // arrived), into the halo ring; at the image's border: BORDER_REPLICATE from the tile's own edge (src/main.cpp:351-354)
-    if (it + 1 < nit) {
-      if (tid < 64) {
-        const int nb = lane == 0 ? (ty > 0 ? bid - tc : -1) : lane == 1 ? (ty < tr - 1 ? bid + tc : -1) : lane == 2 ? (tx > 0 ? bid - 1 : -1)
-                       : lane == 3 ? (tx < tc - 1 ? bid + 1 : -1) : -1;
-        bool sat = nb < 0;
-        int ok = 0;
-        for (int i = 0; i < a.res_poll_cap; ++i) {
-          if (!sat) { const u32x4r_t f = ld_line16(rs->hflag, (unsigned)(nb < 0 ? 0 : nb) * 64u); sat = f.x >= gen && f.x != 0xffffffffu; }
-          if (__builtin_amdgcn_ballot_w64(!sat) == 0ull) { ok = 1; break; }
-          if ((i & 15) == 15 && ld_agent((const unsigned *)&rs->error) != 0u) break;
-          __builtin_amdgcn_s_sleep(2);
+            stamp(it, kStampIt, 7);                                  // master: release issued
+            own = OwnRelease{(int)gen, (int)leave, n1, n2};
+            // everything else the master books comes AFTER the release (off the critical path of the other workgroups).
+            // The last iteration of the launch leaves the sums where the per-launch path expects them: set p0 + executed filled (one
+            // shard per sum), the set behind it clear
+            if (leave) {
+              __hip_atomic_store(&a.chain->v[(phase + 1) & 3][lane], lane == 0 ? q0 : lane == 32 ? q1 : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&a.chain->v[(phase + 2) & 3][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (inside a launch the books are written behind the workgroup's meeting below: on gfx9 a wave's stores count in vmcnt like its
+            // loads, and every conservative `s_waitcnt vmcnt(0)` on wave 0's way into the next iteration would wait for them)
+            if (leave) book(c1, c2, nrm, stop_now, true);
+            else { book_pending = true; book_nrm = nrm; }
+          } else if (lane == 0) st_agent(&rs->error, 1);
         }
-        if (lane == 0) { if (!ok) st_agent(&rs->error, 1); s_flag[0] = ok; }
+        // (a master that gave up has raised the error word and released nobody: every wait below and in the other workgroups sees the
+        // word and leaves)
       }
-      __syncthreads();
-      const int okn = s_flag[0];
-      __syncthreads();
-      if (!okn) { gave_up = true; break; }
-      const double *const hbn = a.res_halo + (size_t)(it & 1) * ntiles * RT_HALO;
-      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) {
-        const int piece = q / RT_W, k = q % RT_W;
-        double v;
-        double *dst;
-        if (piece < 2) {            // top halo rows -2, -1 <- the tile above's bottom two rows
-          dst = S(piece - 2, k);
-          v = ty > 0 ? ld_agent_f64(hbn + (size_t)(bid - tc) * RT_HALO + piece * RT_W + k) : *S(0, k);
-        } else if (piece == 2) {    // bottom halo row TH <- the tile below's top row
-          dst = S(TH, k);
-          v = ty < tr - 1 ? ld_agent_f64(hbn + (size_t)(bid + tc) * RT_HALO + 2 * RT_W + k) : *S(TH - 1, k);
-        } else if (piece < 5) {     // left halo columns -2, -1 <- the left tile's right two columns
-          dst = k < TH ? S(k, piece - 5) : nullptr;
-          v = tx > 0 ? ld_agent_f64(hbn + (size_t)(bid - 1) * RT_HALO + piece * RT_W + k) : *S(k < TH ? k : 0, 0);
-        } else {                    // right halo column TWv <- the right tile's left column
-          dst = k < TH ? S(k, TWv) : nullptr;
-          v = tx < tc - 1 ? ld_agent_f64(hbn + (size_t)(bid + 1) * RT_HALO + 5 * RT_W + k) : *S(k < TH ? k : 0, TWv - 1);
-        }
-        if (dst) *dst = v;
-      }
-      // (the barrier at the top of the next iteration orders these LDS writes before their readers)
+      // the eight waves meet ONCE, behind the release, and thread 0 hands over what it wrote: the master tile polls no release line and
+      // has no round trip left on its way into the next iteration (it used to be the LAST tile into every iteration, 1.3 us behind the median)
+      if (lane == 0) s_flag[wave] = ok_w;
+      if (tid == 0) { s_bc[0] = (double)(own.gen == (int)gen ? own.leave : -1); s_bc[1] = own.c1; s_bc[2] = own.c2; }
+      lds_barrier();
+      int okn = 1;
+#pragma unroll
+      for (int wv = 0; wv < RT_WAVES; ++wv) okn &= s_flag[wv];
+      go_known = (int)s_bc[0];
+      const double k1 = s_bc[1], k2 = s_bc[2];
+      lds_barrier();
+      if (!okn || go_known < 0) { gave_up = true; break; }   // (a neighbour or the master's own collection gave up: the error word is up)
+      if (book_pending) { book(c1, c2, book_nrm, 0, false); book_pending = false; }   // (c1 / c2: still the means this iteration ran with)
+      if (want_borders) { c1 = k1; c2 = k2; }
+      have_go = true;
     }
   }
   if (gave_up) return;
@@ -577,7 +669,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   // then writes its tile back into the ping-pong buffer the per-launch path would hold the result in
   if (executed > 0) {
     double d1, d2;
-    if (wg_wait_go(rs, bid, executed, a, s_bc, d1, d2) < 0) return;
+    if (wg_wait_go(rs, bid, executed, a, s_bc, d1, d2, own) < 0) return;
   }
   // (an even count lands in the buffer the launch read from: every workgroup has long finished reading it -- the first grid
   // barrier lies behind all the tile loads)

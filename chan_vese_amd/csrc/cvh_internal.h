@@ -128,6 +128,7 @@ struct CvhStepArgs {
   int res_t0;                    // index of the launch's first iteration inside the run (= iterations enqueued before it)
   int res_prio;                  // resident kernels: a wave lowers its priority with every quarter of its band (the two waves of a SIMD finish together)
   int res_band_rows;             // rows per wave when every tile has 8 x that many rows (2, 4, 8, 16: straight-line march), else 0
+  int res_go_shift;              // 2^shift tiles of one XCD share a release line (csv_resident_kernel.hip, go_line)
 };
 
 // The ONE way a step / Perona-Malik kernel is launched: KERNEL may be a parenthesised template-id; the trailing

@@ -16,7 +16,7 @@ keys = sorted({k for s in settings for k in s})
 res = np.zeros((len(settings), reps))
 for r in range(reps):
     for i, s in enumerate(settings):
-        for k in keys: ctx.set_option(k, s.get(k, {"chain": 1, "wave_cls": 1, "far_terms": 5, "wave_prio": 1, "wave_sync": -1, "kernel": -1, "wave_occupancy": 5, "wave_cskew": 500, "wave_early": 1, "wave_pol": -1, "lut": 1, "strip_rows": 0, "resident": 0, "near_switch": 1, "wave_xcd": 1, "state": 64, "co_resident": 1}.get(k, 0)))
+        for k in keys: ctx.set_option(k, s.get(k, {"chain": 1, "wave_cls": 1, "far_terms": 5, "wave_prio": 1, "wave_sync": -1, "kernel": -1, "wave_occupancy": 5, "wave_cskew": 500, "wave_early": 1, "wave_pol": -1, "lut": 1, "strip_rows": 0, "resident": 0, "near_switch": 1, "wave_xcd": 1, "state": 64, "co_resident": 1, "res_prio": 1, "res_go_share": 5}.get(k, 0)))
         ctx.warm(steps); ctx.enqueue_steps(16); ctx.sync()
         ctx.warm(steps); ctx.enqueue_steps(steps); ctx.sync()
         res[i, r] = ctx.last_run_ms() * 1e3 / steps

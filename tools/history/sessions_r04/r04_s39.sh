@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4, session 39: the master workgroup's waves split the work (4 poll, 4 store / signal / fetch); A/B against the build before the master changes
+set -o pipefail
+O=gpurun_out/r4s39; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_resident.py tests/test_gpu_resident_fuzz.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+grep -q "rc=0" $O/pytest.log || exit 1
+for i in 1 2; do
+timeout -k 10 200 python tools/resident_timeline.py > $O/resident_timeline_2048_$i.txt 2>&1; tail -9 $O/resident_timeline_2048_$i.txt
+done
+B=tools/experiments/_libs/libchanvese_hip_r04_before_master.so
+for n in 2048 1024 512; do
+N=$n REPS=4 OPTS=resident=1 timeout -k 10 300 python tools/ab_libs.py $B chan_vese_amd/csrc/libchanvese_hip.so > $O/ab_libs_$n.log 2>&1; cat $O/ab_libs_$n.log
+done
+for i in 1 2; do
+  timeout -k 10 200 python bench.py --config C4 --no-cpu-baseline --no-phases > $O/c4_$i.json 2>/dev/null; python -c "
+import json; d=json.load(open('$O/c4_$i.json')); print('csv us/iter', round(d['roofline']['avg_launch_us'],2), 'pm us/step', round(d['pm']['us_per_step'],3), d['checked'])"
+done

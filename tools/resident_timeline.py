@@ -17,7 +17,7 @@ ctx.set_option("debug_times", 1)
 ctx.run(8)
 L = capi.lib()
 L.cvh_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int)]
-buf = np.zeros(nt * 12 + 64, dtype=np.uint64); words = C.c_long(0); nb = C.c_int(0)
+buf = np.zeros(256 * 12 + 64, dtype=np.uint64); words = C.c_long(0); nb = C.c_int(0)
 L.cvh_debug_read(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size, C.byref(words), C.byref(nb))
 w = buf[:nt * 12].reshape(nt, 12).astype(np.int64)
 t0 = w[:, 0].min()
@@ -34,4 +34,15 @@ d = lambda a_, b_: np.median((w[:, b_] - w[:, a_]) / 100.0)
 print("per workgroup (median): set-up %.2f | march (wave 0) %.2f | other waves + reduce %.2f | border stores complete %.2f us" % (d(0, 1), d(1, 2), d(2, 3), d(3, 4)))
 print("last tile's arrival stored %.2f -> master sees all arrivals %.2f -> norm / means %.2f -> release issued %.2f -> seen by the others: p50 %.2f max %.2f ; iteration period (p50) %.2f us" % (
     us(w[:, 3]).max(), us(w[0, 5]), us(w[0, 6]), us(w[0, 7]), np.median(us(w[:, 8])), us(w[:, 8]).max(), np.median((w[:, 8] - w[:, 0]) / 100.0)))
+print("workgroup 0 (the master's own tile): released %.2f | table %.2f | march (wave 0) %.2f | all waves %.2f | borders %.2f | released into the next %.2f us" % tuple(us(w[0, k]) for k in (0, 1, 2, 3, 4, 8)))
+mw = buf[256 * 12:256 * 12 + 16].astype(np.int64)
+if mw[:8].max() > 0:
+    print("master's waves, share of the arrivals complete at: " + "  ".join("w%d %.2f (%d rounds; its tiles arrived by %.2f)" % (
+        k, us(mw[k]), mw[8 + k], us(w[32 * k:32 * k + 32, 3]).max() if 32 * k < nt else 0.0) for k in range(8)))
+mw = buf[256 * 12 + 16:256 * 12 + 40].astype(np.int64)
+for k, t in enumerate((0, 100, 255)):
+    if t < nt and mw[8 * k:8 * k + 8].max() > 0:
+        print("tile %3d: march done by wave  " % t + "  ".join("w%d %.2f" % (v, us(mw[8 * k + v])) for v in range(8)) + "   (released %.2f)" % us(w[t, 0]))
+late = np.argsort(-w[:, 3])[:5]
+print("last five arrivals: " + ", ".join("tile %d at %.2f (released %.2f)" % (t, us(w[t, 3]), us(w[t, 0])) for t in late))
 ctx.close()
