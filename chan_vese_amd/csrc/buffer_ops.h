@@ -36,5 +36,9 @@ __device__ __forceinline__ void buf_store_f64(double v, __amdgpu_buffer_rsrc_t r
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
 }
 
+// A workgroup barrier that orders LDS only.  __syncthreads() also waits for every global store the wave has in flight -- on gfx9 stores count
+// in vmcnt like loads, and a wave's memory operations return in order -- so a wave that has just sent its border to the neighbours (resident
+// kernels) would sit at the barrier until the last store is acknowledged (0.7-1.5 us) before it may issue the loads it is really waiting for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 }  // namespace cvh_dev

@@ -88,6 +88,9 @@ __device__ __forceinline__ void st_line16_u64(void *base, unsigned byte_off, uns
 __device__ __forceinline__ long long line16_i64(u32x4r_t v) { return (long long)(((unsigned long long)v.w << 32) | v.z); }
 __device__ __forceinline__ double line16_f64(u32x4r_t v) { return __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z)); }
 
+// (lds_barrier(), buffer_ops.h: the workgroup barrier that orders LDS only -- the master's wave 0 has its release and its bookkeeping
+// stores under way on the path from one iteration into the next)
+
 // Release lines are shared: workgroups are dealt to the 8 XCDs round-robin, and 2^shift tiles of one XCD read the same line (shift 0: a
 // line per tile).  The master's release is then 2 * 256 / 2^shift sixteen-byte stores instead of 512 -- one wave needs 1.2 us to drain 512
 // of them (the last tile saw its release 1.3 us after the first store was issued, profiles/r04_C4/resident_timeline_2048_master1.txt).
@@ -96,11 +99,6 @@ __device__ __forceinline__ int go_lines(int ntiles, int shift) { return shift >=
 
 // Thread 0 polls this workgroup's release line until both halves carry generation >= `gen` (bounded); the workgroup meets at a
 // barrier.  Returns the leave bit (or -1: gave up) and the region means the line carries.
-// A workgroup barrier that orders LDS only: __syncthreads() also waits for every global store the wave has in flight, and on the way
-// from one iteration into the next the master's wave 0 has its bookkeeping stores under way (some of them to pinned HOST memory: 1.7 us
-// until the last one is acknowledged -- profiles/r04_C4/resident_timeline_2048_master1.txt, first collection).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // (`own`: the master workgroup wrote this very release itself -- thread 0 passes what it wrote, own.gen = its generation, and no line is polled)
 struct OwnRelease { int gen, leave; double c1, c2; };
 __device__ __forceinline__ int wg_wait_go(const CvhResident *rs, int bid, int gen, const CvhStepArgs &a, double *s_bc /*[4]*/, double &c1, double &c2,

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
         if (g_dst[j] >= 0 && !(need & (1u << j))) sI[g_dst[j]] = g_src[j] >= 0 ? v[j] : sI[~g_src[j]];
       }
     }
-    __syncthreads();
+    lds_barrier();     // (LDS only, here and below: the border stores of the step before may still be in flight -- buffer_ops.h; measured: no difference)
     if (s_flag[0] != 0) { gave_up = true; break; }
     stamp(st, kStampStep, 2);                                 // halo ring in LDS
 
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
       if (rb0 + NR == TH) { st_row(keep[NK - 2], 2u); st_row(keep[NK - 1], 3u); }
     }
     stamp(st, kStampStep, 3);                                 // (thread 0's wave) band computed
-    __syncthreads();
+    lds_barrier();
     stamp(st, kStampStep, 4);                                 // all waves
     // ---- 3. the band's first and last rows replace the old ones
     if (lane_valid) {
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
         if ((k < 2 || k >= NR - 2) && rb0 + k < TH) *reinterpret_cast<double2_t *>(S(rb0 + k, ca)) = keep[k < 2 ? k : k - (NR - NK)];
       }
     }
-    __syncthreads();
+    lds_barrier();
     stamp(st, kStampStep, 5);                                 // tile rewritten
     // ---- 4. the border of a tile that is not full: from LDS
     if (st + 1 < nsteps && !pub_regs) {
