@@ -155,6 +155,28 @@ def test_resident_straight_line_flavours_are_the_generic_march_bit_for_bit(capi,
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("shape", [(128, 128), (384, 640), (1024, 1152), (2048, 2048)])
+def test_resident_release_lines_shared_or_not_same_results(capi, shape):
+    """Round 4: the master releases a line per XCD (option "res_go_share" = 5; 0 = a line per tile as in round 3, 6 = one line for all).  Which line
+    a tile polls is plumbing: level set, trace and the stop iteration are the same bits for every setting -- one tile, 15, 72 and 256 tiles, a chunk
+    boundary in the middle, a stop rule that fires inside the second launch."""
+    h, w = shape
+    img = synth.disk(max(h, w), 200, 50, noise=20, seed=11, h=h, w=w)
+    outs = []
+    for share in (5, 0, 3, 6):
+        with capi.Context(h, w, 1, capi.make_params(tol=0, nu=0.01)) as ctx:
+            ctx.set_option("resident", 1); ctx.set_option("res_go_share", share); ctx.set_option("trace", 40)
+            assert ctx.launch_info()["kernel"].startswith("csv_resident_kernel<")
+            ctx.set_image([img]); ctx.init_checkerboard()
+            ctx.enqueue_steps(9); ctx.enqueue_steps(14); ctx.sync()
+            outs.append((ctx.get_levelset(), ctx.get_trace(23)))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+    with pytest.raises(Exception):
+        with capi.Context(h, w, 1, capi.make_params(tol=0)) as ctx:
+            ctx.set_option("res_go_share", 7)
+
+
 def test_automatic_flow_steps_aside_for_a_batch(capi, oracle):
     """Round 4: the automatic choice of the resident flow looks at the device's live contexts.  One 256^2 context alone: the resident kernel.
     Two contexts that hold an image and a level set (a batch): cooperative launches of different contexts would serialise (tools/batch_probe.py:
