@@ -1,6 +1,6 @@
 """A/B of OPTION SETS on the Perona-Malik phase inside ONE process: each setting gets its own context on the same image, the contexts take
 turns; prints HIP-event us per time step per setting and round, and says whether the planes are the same bytes.
-usage: pm_ab_opts.py "pm_kernel=4" "pm_kernel=4,pm_res_waves=4" ...   [N=2048 H= W= REPS=4 STEPS=400 MATH=2]"""
+usage: pm_ab_opts.py "pm_kernel=4" "pm_kernel=4,res_prio=0" ...   [N=2048 H= W= REPS=4 STEPS=400 MATH=2]"""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np
