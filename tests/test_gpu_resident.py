@@ -177,6 +177,24 @@ def test_resident_release_lines_shared_or_not_same_results(capi, shape):
             ctx.set_option("res_go_share", 7)
 
 
+def test_priority_by_quarters_is_scheduling_only(capi):
+    """Option "res_prio" (both resident kernels: a wave lowers its s_setprio level with every quarter of its band) changes WHEN a wave runs, never what
+    it computes: level set, trace and the smoothed plane are the same bits with and without."""
+    n = 1024
+    img = synth.disk(n, 200, 50, noise=25, seed=13)
+    outs = []
+    for prio in (1, 0):
+        with capi.Context(n, n, 1, capi.make_params(tol=0, nu=0.01)) as ctx:
+            ctx.set_option("resident", 1); ctx.set_option("res_prio", prio); ctx.set_option("pm_kernel", 4); ctx.set_option("trace", 20)
+            ctx.set_image([img]); ctx.perona_malik(30.0, 0.25, 5.0)
+            smooth = ctx.get_image()[0]
+            assert ctx.launch_info(1)["kernel"].startswith("pm_resident_kernel<") and ctx.launch_info()["kernel"].startswith("csv_resident_kernel<")
+            ctx.init_checkerboard()
+            assert ctx.run(20)[0] == 20
+            outs.append((smooth, ctx.get_levelset(), ctx.get_trace(20)))
+    assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1]))
+
+
 def test_automatic_flow_steps_aside_for_a_batch(capi, oracle):
     """Round 4: the automatic choice of the resident flow looks at the device's live contexts.  One 256^2 context alone: the resident kernel.
     Two contexts that hold an image and a level set (a batch): cooperative launches of different contexts would serialise (tools/batch_probe.py:
