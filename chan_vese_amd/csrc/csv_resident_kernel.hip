@@ -8,15 +8,15 @@
 // the first row computes, the drain of the last waves, every level-set byte through the memory system twice -- is paid once per
 // chunk; what crosses workgroups per iteration is
 //   * the tile's border rows / columns (the 7-point cross reaches 2 up / left, 1 down / right: 6 x 128 doubles per tile), through a
-//     double-buffered global halo buffer, written and read with sc1 (agent scope);
+//     double-buffered global halo buffer, written and read with sc1 (agent scope), two doubles per 16-byte store / load;
 //   * ONE grid barrier with a master.  A tile ARRIVES with three 16-byte agent-scope stores into its own 64-byte line {generation, sum
 //     u_diff^2} {generation, sum H'} {generation, sum I H'} -- the last two as chain mode's fixed-point integers (chain_device.h) -- right
 //     behind its reduction, before its border stores (those get their own signal line: only the neighbours wait for them).  Workgroup
-//     0 is the master: its eight waves watch 32 arrival lines each without workgroup barriers, wave 0 adds the integers (exact,
-//     order-free: the totals the per-launch path's atomic adds produce), books the iteration (norm, stop rule src/main.cpp:1000,
-//     trace row) and RELEASES everybody with one line per workgroup that carries the leave bit and the region means of the new level
-//     set (every workgroup polls its own line: same-address polling does not scale, tools/experiments/persist/README.md).  The stop
-//     rule therefore fires at the reference's iteration with no extra iteration computed, and no atomic is issued inside the launch.
+//     0 is the master: four of its waves watch 64 arrival lines each without workgroup barriers (the other four do the tile's own border
+//     work meanwhile), wave 0 adds the integers (exact, order-free: the totals the per-launch path's atomic adds produce), books the
+//     iteration (norm, stop rule src/main.cpp:1000, trace row) and RELEASES everybody with one line per XCD that carries the leave bit and
+//     the region means of the new level set.  The stop rule therefore fires at the reference's iteration with no extra iteration computed,
+//     and no atomic is issued inside the launch.  (What the barrier costs and how it got here: DESIGN.md 4.1b.)
 // Every wait is a bounded poll: a workgroup that gives up raises CvhResident::error and leaves, and so does everybody waiting
 // for it -- the grid always drains; the host reports the error at the next synchronisation.
 //
@@ -453,7 +453,8 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     const unsigned gen = (unsigned)(it + 1);
     // three 16-byte lines {generation, payload}: sum u_diff^2, and the fixed-point sums the next iteration's means come from (distinct
     // addresses: 256 arrivals on one counter serialise for 6 us).  The arrival does not wait for the border stores below: the master needs
-    // the sums only, the neighbours get their own signal.
+    // the sums only, the neighbours get their own signal.  (Two pieces -- the 64-bit sum of H' split over the spare words -- were tried: a third
+    // fewer arrival stores and polls, and no faster: 13.03 vs 12.92 us at 2048^2, 5.73 vs 5.39 at 512^2, gpurun_out/r4s50.)
     if (tid < 3) {
       double t = sred[tid];
 #pragma unroll
@@ -466,15 +467,21 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     // border signal; then the neighbours' borders of u(it + 1) -- they exist as soon as the up-to-four neighbours have stored THEIR signal --
     // go into the halo ring while the barrier completes; at the image's border: BORDER_REPLICATE from the tile's own edge (src/main.cpp:351-354)
     double *const hb = halo_mine[it & 1];
-    auto store_border = [&](int q) {
+    auto border_value = [&](int q) -> double {
       const int piece = q / RT_W, k = q % RT_W;
-      double v;
-      if (piece < 2) v = *S(TH - 2 + piece, k);                    // bottom two rows   (TH >= 2: host)
-      else if (piece == 2) v = *S(0, k);                           // top row
-      else if (piece < 5) v = *S(k < TH ? k : 0, TWv - 5 + piece);  // right two columns: TWv - 2, TWv - 1
-      else v = *S(k < TH ? k : 0, 0);                              // left column
-      st_agent_f64(hb + q, v);
+      if (piece < 2) return *S(TH - 2 + piece, k);                    // bottom two rows   (TH >= 2: host)
+      if (piece == 2) return *S(0, k);                                // top row
+      if (piece < 5) return *S(k < TH ? k : 0, TWv - 5 + piece);      // right two columns: TWv - 2, TWv - 1
+      return *S(k < TH ? k : 0, 0);                                   // left column
     };
+    // two neighbouring elements of a piece with ONE 16-byte store (RT_W is even: a pair never straddles two pieces): 384 stores per tile
+    auto store_border = [&](int p) {
+      const double v0 = border_value(2 * p), v1 = border_value(2 * p + 1);
+      const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4r_t{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)}, make_rsrc(hb, 0x7fffffffu),
+                                             (unsigned)p * 16u, 0u, 16 /* sc1 */);
+    };
+    constexpr int kPairs = 3 * RT_W;
     const bool want_borders = it + 1 < nit;
     const int nb_lane = lane == 0 ? (ty > 0 ? bid - tc : -1) : lane == 1 ? (ty < tr - 1 ? bid + tc : -1) : lane == 2 ? (tx > 0 ? bid - 1 : -1)
                         : lane == 3 ? (tx < tc - 1 ? bid + 1 : -1) : -1;          // lanes 0-3 of a polling wave watch one neighbour each
@@ -492,29 +499,38 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
     };
     const double *const hbn = a.res_halo + (size_t)(it & 1) * ntiles * RT_HALO;
     // element q of the 6 x 128 border: its value (a neighbour's store, or the tile's own edge) into the halo cell it belongs to
-    auto fetch = [&](int q) {
-      const int piece = q / RT_W, k = q % RT_W;
-      double *dst;
-      double v;
+    // pair p of the 6 x 128 border (elements 2p, 2p + 1 of one piece): the values (a neighbour's 16-byte store, or the tile's own edge) into
+    // the two halo cells they belong to
+    auto fetch = [&](int p) {
+      const int q = 2 * p, piece = q / RT_W, k = q % RT_W;
+      double *d0, *d1;
+      int nb;              // the neighbour the piece comes from (-1: the image ends here)
+      double e0, e1;       // ... and then: the tile's own edge
       if (piece < 2) {            // top halo rows -2, -1 <- the tile above's bottom two rows
-        dst = S(piece - 2, k);
-        v = ty > 0 ? ld_agent_f64(hbn + (size_t)(bid - tc) * RT_HALO + piece * RT_W + k) : *S(0, k);
+        d0 = S(piece - 2, k); d1 = S(piece - 2, k + 1);
+        nb = ty > 0 ? bid - tc : -1; e0 = *S(0, k); e1 = *S(0, k + 1);
       } else if (piece == 2) {    // bottom halo row TH <- the tile below's top row
-        dst = S(TH, k);
-        v = ty < tr - 1 ? ld_agent_f64(hbn + (size_t)(bid + tc) * RT_HALO + 2 * RT_W + k) : *S(TH - 1, k);
+        d0 = S(TH, k); d1 = S(TH, k + 1);
+        nb = ty < tr - 1 ? bid + tc : -1; e0 = *S(TH - 1, k); e1 = *S(TH - 1, k + 1);
       } else if (piece < 5) {     // left halo columns -2, -1 <- the left tile's right two columns
-        dst = k < TH ? S(k, piece - 5) : nullptr;
-        v = tx > 0 ? ld_agent_f64(hbn + (size_t)(bid - 1) * RT_HALO + piece * RT_W + k) : *S(k < TH ? k : 0, 0);
+        d0 = k < TH ? S(k, piece - 5) : nullptr; d1 = k + 1 < TH ? S(k + 1, piece - 5) : nullptr;
+        nb = tx > 0 ? bid - 1 : -1; e0 = *S(k < TH ? k : 0, 0); e1 = *S(k + 1 < TH ? k + 1 : 0, 0);
       } else {                    // right halo column TWv <- the right tile's left column
-        dst = k < TH ? S(k, TWv) : nullptr;
-        v = tx < tc - 1 ? ld_agent_f64(hbn + (size_t)(bid + 1) * RT_HALO + 5 * RT_W + k) : *S(k < TH ? k : 0, TWv - 1);
+        d0 = k < TH ? S(k, TWv) : nullptr; d1 = k + 1 < TH ? S(k + 1, TWv) : nullptr;
+        nb = tx < tc - 1 ? bid + 1 : -1; e0 = *S(k < TH ? k : 0, TWv - 1); e1 = *S(k + 1 < TH ? k + 1 : 0, TWv - 1);
       }
-      if (dst) *dst = v;
+      if (nb >= 0) {
+        const u32x4r_t v = ld_line16(hbn + (size_t)nb * RT_HALO, (unsigned)p * 16u);
+        e0 = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+        e1 = line16_f64(v);
+      }
+      if (d0) *d0 = e0;
+      if (d1) *d1 = e1;
     };
 
     if (bid != 0) {
       // ---- an ordinary tile: border, border signal, the neighbours' borders; the release is polled at the top of the next iteration
-      for (int q = tid; q < 6 * RT_W; q += RT_THREADS) store_border(q);
+      for (int p = tid; p < kPairs; p += RT_THREADS) store_border(p);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       stamp(it, kStampIt, 4);                                    // borders have reached memory
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         const int okn = s_flag[0];
         __syncthreads();
         if (!okn) { gave_up = true; break; }
-        for (int q = tid; q < 6 * RT_W; q += RT_THREADS) fetch(q);
+        for (int p = tid; p < kPairs; p += RT_THREADS) fetch(p);
         // (the barrier at the top of the next iteration orders these LDS writes before their readers)
       }
     } else {
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       static_assert(64 * kPollWaves >= CVH_RESIDENT_MAX_TILES, "the master's polling waves watch 64 arrival lines each");
       int ok_w = 1;                  // (wave-uniform) this wave's errand went well
       if (wave >= kPollWaves) {
-        for (int q = tid - 64 * kPollWaves; q < 6 * RT_W; q += kWorkThreads) store_border(q);
+        for (int p = tid - 64 * kPollWaves; p < kPairs; p += kWorkThreads) store_border(p);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0 && __hip_atomic_fetch_add(&s_flag[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == (RT_WAVES - kPollWaves) * (int)gen) {
           if (a.dbg_times && it == kStampIt) a.dbg_times[(size_t)bid * 12 + 4] = __builtin_amdgcn_s_memrealtime();
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         }
         if (want_borders) {
           ok_w = neighbours_arrived();
-          if (ok_w) for (int q = tid - 64 * kPollWaves; q < 6 * RT_W; q += kWorkThreads) fetch(q);
+          if (ok_w) for (int p = tid - 64 * kPollWaves; p < kPairs; p += kWorkThreads) fetch(p);
         }
         if (lane == 0 && !ok_w) st_agent(&rs->error, 1);
       } else {

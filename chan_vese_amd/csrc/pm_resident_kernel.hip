@@ -52,7 +52,9 @@ struct PmResSmem {
   static constexpr int off_I = 0;                                          // (PT_HMAX + 4) rows x PT_PITCH: tile rows -2 .. TH+1
   static constexpr int off_edge = off_I + (PT_HMAX + 4) * PT_PITCH;       // per wave: g of tile column -1 [16], of tile column TW [16]
   static constexpr int off_flag = off_edge + PT_WAVES * 32;
-  static constexpr int doubles = off_flag + 2;
+  static constexpr int off_stage = off_flag + 2;                          // per wave: the four edge columns of up to four rows [4][4], on their way to the border buffer
+  static constexpr int off_rstage = off_stage + PT_WAVES * 16;             // per wave: one row of the tile [PT_W] on its way to the border buffer (waves 0 and 7 of a full tile)
+  static constexpr int doubles = off_rstage + PT_WAVES * PT_W;
   static constexpr size_t bytes = (size_t)doubles * sizeof(double);
 };
 static_assert(PmResSmem::bytes <= 160 * 1024, "the tile with its halo ring must fit one CU's LDS");
@@ -87,6 +89,8 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
   double *sI = smem + L::off_I;
   double *sEdge = smem + L::off_edge + 32 * (threadIdx.x >> 6);
   int *s_flag = (int *)(smem + L::off_flag);
+  double *sStage = smem + L::off_stage + 16 * (threadIdx.x >> 6);
+  double *sRow = smem + L::off_rstage + PT_W * (threadIdx.x >> 6);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,9 +276,8 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
     unsigned char *const hb_mine = reinterpret_cast<unsigned char *>(a.res_halo) + ((size_t)(st & 1) * ntiles + bid) * PT_HALO * 16u;
     const __amdgpu_buffer_rsrc_t rh = make_rsrc(hb_mine, PT_HALO * 16u);
     const unsigned tag_lo = (unsigned)(st + 1), tag_hi = a.res_serial;      // what the neighbours wait for before their step st + 1
-    // left two columns (lane 0 -> pieces 4, 5) and right two (lane 63 -> pieces 6, 7), row by row; every other lane's store is dropped
+    // left two columns (lane 0 -> pieces 4, 5) and right two (lane 63 -> pieces 6, 7)
     const bool col_lane = pub_regs && (lane == 0 || lane == 63);
-    const unsigned vcol = col_lane ? ((lane == 0 ? 4u : 6u) * PT_W + (unsigned)rb0) * 16u : kOobOffset;
     {
       Row x0 = load_row(rb0), xp = load_row(rb0 + 1), xq = load_row(rb0 + 2);    // (xq: one row ahead of its use -- LDS latency)
       HRow h0, hp;
@@ -344,9 +347,21 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
         if (k < 2) keep[k] = double2_t{ox, oy};
         else if (k >= NR - 2) keep[k - (NR - NK)] = double2_t{ox, oy};
         else if (lane_valid && i < TH) *reinterpret_cast<double2_t *>(S(i, ca)) = double2_t{ox, oy};
-        if (col_lane) {      // (two active lanes: a 16-byte store of 64 lanes, 62 of them dropped for their offset, costs the memory pipe 4x a masked one)
-          __builtin_amdgcn_raw_buffer_store_b128(tagged(ox, tag_lo, tag_hi), rh, vcol + (unsigned)k * 16u, 0u, 16 /* sc1 */);
-          __builtin_amdgcn_raw_buffer_store_b128(tagged(oy, tag_lo, tag_hi), rh, vcol + (unsigned)(PT_W + k) * 16u, 0u, 16);
+        // The tile's edge columns leave four rows at a time (round 4): lanes 0 / 63 leave their two values of a row in the wave's staging
+        // array, and behind every fourth row sixteen lanes store the quarter's 4 x 4 entries -- four rows of a piece are one 64-byte line of
+        // the border buffer, written once instead of four times by two-lane stores (32 store instructions per band and step were 2-lane ones).
+        constexpr int QS = NR >= 4 ? 4 : NR;          // rows per batch (eight: no different, 7.15 vs 7.19 us per step at 2048^2)
+        if (col_lane) *reinterpret_cast<double2_t *>(sStage + (lane == 0 ? 0 : 8) + 2 * (k % QS)) = double2_t{ox, oy};     // [side][row of the batch][column]
+        if (pub_regs && k % QS == QS - 1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (lane < 4 * QS) {
+            const int pc = lane / QS, rr = lane % QS;                 // piece 4 + pc (columns 0, 1, TW-2, TW-1), row of the batch
+            const double v = sStage[(pc >> 1) * 8 + 2 * rr + (pc & 1)];
+            __builtin_amdgcn_raw_buffer_store_b128(tagged(v, tag_lo, tag_hi), rh, ((unsigned)(4 + pc) * PT_W + (unsigned)(rb0 + k - (QS - 1) + rr)) * 16u, 0u, 16 /* sc1 */);
+          }
+          __builtin_amdgcn_wave_barrier();        // (the next batch's writes stay behind these reads)
         }
         x0 = xp; xp = xpp;
         h0 = hp; hp = hpp;
@@ -357,9 +372,17 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
     }
     // ---- the top / bottom two rows of a full tile straight from the registers: the stores travel while the workgroup meets
     if (pub_regs) {
+      // (through the wave's staging row, so that a store instruction writes 64 NEIGHBOURING entries -- 1 KiB of the border buffer in one
+      // piece -- instead of every other one: lane l holds columns 2l and 2l + 1, and stores columns l and 64 + l)
       auto st_row = [&](double2_t v, unsigned piece) {
-        __builtin_amdgcn_raw_buffer_store_b128(tagged(v.x, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)ca) * 16u, 0u, 16 /* sc1 */);
-        __builtin_amdgcn_raw_buffer_store_b128(tagged(v.y, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)ca + 1u) * 16u, 0u, 16);
+        *reinterpret_cast<double2_t *>(sRow + ca) = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double lo = sRow[lane], hi = sRow[64 + lane];
+        __builtin_amdgcn_raw_buffer_store_b128(tagged(lo, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)lane) * 16u, 0u, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128(tagged(hi, tag_lo, tag_hi), rh, (piece * PT_W + 64u + (unsigned)lane) * 16u, 0u, 16);
+        __builtin_amdgcn_wave_barrier();        // (the next row's writes stay behind these reads)
       };
       if (rb0 == 0) { st_row(keep[0], 0u); st_row(keep[1], 1u); }
       if (rb0 + NR == TH) { st_row(keep[NK - 2], 2u); st_row(keep[NK - 1], 3u); }
