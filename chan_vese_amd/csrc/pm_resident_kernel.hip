@@ -278,6 +278,18 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
     const unsigned tag_lo = (unsigned)(st + 1), tag_hi = a.res_serial;      // what the neighbours wait for before their step st + 1
     // left two columns (lane 0 -> pieces 4, 5) and right two (lane 63 -> pieces 6, 7)
     const bool col_lane = pub_regs && (lane == 0 || lane == 63);
+    // (through the wave's staging row, so that a store instruction writes 64 NEIGHBOURING entries -- 1 KiB of the border buffer in one
+    // piece -- instead of every other one: lane l holds columns 2l and 2l + 1, and stores columns l and 64 + l)
+    auto st_row = [&](double2_t v, unsigned piece) {
+      *reinterpret_cast<double2_t *>(sRow + ca) = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double lo = sRow[lane], hi = sRow[64 + lane];
+      __builtin_amdgcn_raw_buffer_store_b128(tagged(lo, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)lane) * 16u, 0u, 16 /* sc1 */);
+      __builtin_amdgcn_raw_buffer_store_b128(tagged(hi, tag_lo, tag_hi), rh, (piece * PT_W + 64u + (unsigned)lane) * 16u, 0u, 16);
+      __builtin_amdgcn_wave_barrier();        // (the next row's writes stay behind these reads)
+    };
     {
       Row x0 = load_row(rb0), xp = load_row(rb0 + 1), xq = load_row(rb0 + 2);    // (xq: one row ahead of its use -- LDS latency)
       HRow h0, hp;
@@ -363,6 +375,9 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
           }
           __builtin_amdgcn_wave_barrier();        // (the next batch's writes stay behind these reads)
         }
+        // (the tile's top two rows leave as soon as they exist: two store instructions less in the burst at the end of the step, which is
+        // when the entries everybody waits for -- the last rows -- are on their way)
+        if (k == 1 && pub_regs && rb0 == 0) { st_row(keep[0], 0u); st_row(keep[1], 1u); }
         x0 = xp; xp = xpp;
         h0 = hp; hp = hpp;
         g0a = gpa; g0b = gpb;
@@ -372,19 +387,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
     }
     // ---- the top / bottom two rows of a full tile straight from the registers: the stores travel while the workgroup meets
     if (pub_regs) {
-      // (through the wave's staging row, so that a store instruction writes 64 NEIGHBOURING entries -- 1 KiB of the border buffer in one
-      // piece -- instead of every other one: lane l holds columns 2l and 2l + 1, and stores columns l and 64 + l)
-      auto st_row = [&](double2_t v, unsigned piece) {
-        *reinterpret_cast<double2_t *>(sRow + ca) = v;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double lo = sRow[lane], hi = sRow[64 + lane];
-        __builtin_amdgcn_raw_buffer_store_b128(tagged(lo, tag_lo, tag_hi), rh, (piece * PT_W + (unsigned)lane) * 16u, 0u, 16 /* sc1 */);
-        __builtin_amdgcn_raw_buffer_store_b128(tagged(hi, tag_lo, tag_hi), rh, (piece * PT_W + 64u + (unsigned)lane) * 16u, 0u, 16);
-        __builtin_amdgcn_wave_barrier();        // (the next row's writes stay behind these reads)
-      };
-      if (rb0 == 0) { st_row(keep[0], 0u); st_row(keep[1], 1u); }
+      if (rb0 == 0 && NR < 2) { st_row(keep[0], 0u); st_row(keep[1], 1u); }      // (NR >= 2: they left behind row 1, above)
       if (rb0 + NR == TH) { st_row(keep[NK - 2], 2u); st_row(keep[NK - 1], 3u); }
     }
     stamp(st, kStampStep, 3);                                 // (thread 0's wave) band computed
