@@ -461,7 +461,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       for (int wv = 1; wv < RT_WAVES; ++wv) t += sred[wv * 3 + tid];   // fixed order
       const unsigned long long payload = tid == 0 ? (unsigned long long)__double_as_longlong(t)
                                        : (unsigned long long)__double2ll_rn(t * a.chain_scale[tid - 1]);
-      st_line16_u64(rs->flag, (unsigned)bid * 64u + 16u * (unsigned)tid, gen, 0u, payload);
+      st_line16_u64(rs->flag, ((unsigned)tid * CVH_RESIDENT_MAX_TILES + (unsigned)bid) * 16u, gen, 0u, payload);   // piece-major: the master's polls read neighbouring entries
     }
     // ---- what crosses to the neighbours: the tile's border (6 x 128 doubles, agent-scope stores) and, once those are acknowledged, the
     // border signal; then the neighbours' borders of u(it + 1) -- they exist as soon as the up-to-four neighbours have stored THEIR signal --
@@ -585,9 +585,9 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         bool ok = !have;             // (per lane, sticky: a line that has arrived is not read again -- the last rounds poll the stragglers only)
         for (int round = 0; round < a.res_poll_cap; ++round) {
           if (!ok) {
-            fa = ld_line16(rs->flag, (unsigned)b * 64u);
-            fb = ld_line16(rs->flag, (unsigned)b * 64u + 16u);
-            fc = ld_line16(rs->flag, (unsigned)b * 64u + 32u);
+            fa = ld_line16(rs->flag, (unsigned)b * 16u);
+            fb = ld_line16(rs->flag, (CVH_RESIDENT_MAX_TILES + (unsigned)b) * 16u);
+            fc = ld_line16(rs->flag, (2u * CVH_RESIDENT_MAX_TILES + (unsigned)b) * 16u);
           }
           ok = !have || (tagged(fa) && tagged(fb) && tagged(fc));
           rounds = round + 1;

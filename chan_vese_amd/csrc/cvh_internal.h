@@ -47,10 +47,11 @@ constexpr int CVH_RESIDENT_MAX_TILES = 256;     // the master's eight waves watc
 struct CvhResident {
   int error;            // a bounded wait gave up (a workgroup was not resident, or a fault): the launch drains, the host reports it
   unsigned pad[15];
-  // one 64-byte line per tile, written as THREE 16-byte agent-scope stores {generation, 0, payload}: sum u_diff^2 of the tile (double),
-  // then its fixed-point sums of H - 1/2 and I (H - 1/2) (chain_device.h's integers): the tile has finished iteration generation - 1 of
-  // the launch.  The master adds the integers itself (exact, order-free): no atomics inside the launch, and the arrival does not wait for
-  // the border stores (arrivals on distinct addresses do not serialise)
+  // three 16-byte pieces per tile {generation, 0, payload}, written with agent-scope stores: sum u_diff^2 of the tile (double), then its
+  // fixed-point sums of H - 1/2 and I (H - 1/2) (chain_device.h's integers): the tile has finished iteration generation - 1 of the launch.
+  // PIECE-MAJOR -- piece p of tile t at entry p * CVH_RESIDENT_MAX_TILES + t -- so that a poll instruction of the master reads 64 neighbouring
+  // entries (1 KiB) and not 16 bytes of 64 different lines.  The master adds the integers itself (exact, order-free): no atomics inside the
+  // launch, and the arrival does not wait for the border stores (arrivals on distinct addresses do not serialise)
   unsigned flag[CVH_RESIDENT_MAX_TILES * 16];
   // one 64-byte line per tile, written by the master as two 16-byte stores {generation, leave, c1} {generation, leave, c2}: the release
   // behind iteration generation - 1 and the region means of the level set it produced
