@@ -214,6 +214,10 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
   };
   const int nsteps = a.res_steps;
   bool gave_up = false;
+  u32x4s_t pre[PT_GATHER];                 // the first poll of the next step's ring cells (issued behind the march)
+  bool have_pre = false;
+#pragma unroll
+  for (int j = 0; j < PT_GATHER; ++j) pre[j] = u32x4s_t{0u, 0u, 0u, 0u};
   for (int st = 0; st < nsteps; ++st) {
     stamp(st, kStampStep, 0); stamp(st, kStampStep + 1, 8);
     // ---- 1. the neighbours' borders of the previous step into the halo ring.  No signal to wait for: every entry of the border buffer
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
 #pragma unroll
         for (int j = 0; j < PT_GATHER; ++j) {
           if (need & (1u << j)) {
-            const u32x4s_t c = ld_line16(hb, (unsigned)g_src[j] * 16u);
+            const u32x4s_t c = (i == 0 && have_pre) ? pre[j] : ld_line16(hb, (unsigned)g_src[j] * 16u);    // (the first look was taken when the previous step's march had ended)
             if (c.z == want_lo && c.w == want_hi) { v[j] = __longlong_as_double((long long)(((unsigned long long)c.y << 32) | c.x)); need &= ~(1u << j); }
           }
         }
@@ -393,6 +397,15 @@ __global__ __launch_bounds__(PT_THREADS, 1) void pm_resident_kernel(const CvhPmA
     stamp(st, kStampStep, 3);                                 // (thread 0's wave) band computed
     lds_barrier();
     stamp(st, kStampStep, 4);                                 // all waves
+    // the first look at the NEXT step's ring cells: asked for here, taken when that step begins -- the round trip passes while the rows at the
+    // band's ends are rewritten and the workgroup meets again
+    have_pre = false;
+    if (st + 1 < nsteps) {
+      const unsigned char *const hbn = reinterpret_cast<const unsigned char *>(a.res_halo) + (size_t)(st & 1) * ntiles * PT_HALO * 16u;
+#pragma unroll
+      for (int j = 0; j < PT_GATHER; ++j) if (g_dst[j] >= 0 && g_src[j] >= 0) pre[j] = ld_line16(hbn, (unsigned)g_src[j] * 16u);
+      have_pre = true;
+    }
     // ---- 3. the band's first and last rows replace the old ones
     if (lane_valid) {
 #pragma unroll
