@@ -255,6 +255,28 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
   bool have_go = false;      // (workgroup-uniform) the release into the next iteration was handed over inside the workgroup
   int go_known = -1;
   if (bid == 0 && tid == 0) { rs->pad[0] = (unsigned)t_first; rs->pad[1] = (unsigned)nit; rs->pad[2] = (unsigned)a.st->steps_done; }   // (diagnostic record of the launch)
+  // ---- what an iteration reads before any wave writes and that does not wait for the release (c1 / c2): every wave takes the rows around
+  // its band into registers, one thread per row computes the normalised x-gradient of tile column -1 (nobody owns that column; lane 0 needs
+  // it for column 0), and ny of the row above the band.  Called when the tile and its halo ring are complete: before the loop, and at the end
+  // of an iteration behind the fetch of the neighbours' borders -- off the path from the release into the march.
+  double2_t p_um = {0.0, 0.0}, p_u0 = {0.0, 0.0}, p_ubot = {0.0, 0.0};
+  double p_uw = 0.0, p_ue = 0.0, p_nypa = 0.0, p_nypb = 0.0;
+  auto pre_reads = [&]() {
+    if (tid >= 256 && tid - 256 < TH) snxl[tid - 256] = norm(*S(tid - 256, 0), *S(tid - 256, -2), *S(tid - 256, -1));
+    const double2_t um2_0 = *reinterpret_cast<const double2_t *>(S(rb0 - 2, ca));
+    p_um = *reinterpret_cast<const double2_t *>(S(rb0 - 1, ca));
+    p_u0 = *reinterpret_cast<const double2_t *>(S(rb0, ca));
+    p_ubot = *reinterpret_cast<const double2_t *>(S(rb1, ca));
+    p_uw = *S(rb0, ca - 1); p_ue = *S(rb0, ca + 2);
+    const double2_t u1st = *reinterpret_cast<const double2_t *>(S(rb0 + 1 < rb1 ? rb0 + 1 : rb0, ca));   // row rb0 + 1 (own band, if it has one)
+    if (rb1 > rb0) {
+      p_nypa = norm(p_u0.x, um2_0.x, p_um.x); p_nypb = norm(p_u0.y, um2_0.y, p_um.y);   // ny at row rb0 - 1
+      if (r0 + rb0 == 0) {   // kappa_y(0, .) = 0 (:372): ny_prev := row 0's own ny, the very expression the row uses
+        const double2_t up0 = (rb0 + 1 < rb1) ? u1st : p_ubot;
+        p_nypa = norm(up0.x, p_um.x, p_u0.x); p_nypb = norm(up0.y, p_um.y, p_u0.y);
+      }
+    }
+  };
   for (it = 0; it < nit; ++it) {
     const int phase = (a.chain_phase + it) & 3;
     // ---- the release behind iteration it - 1: leave bit and the region means of u(it); the halos were fetched while waiting
@@ -273,15 +295,12 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       slut[2 * tid] = __builtin_fma(reg, a.beta, a.gamma);
       slut[2 * tid + 1] = v;
     }
-    // ---- normalised x-gradient of tile column -1, one thread per row (nobody owns that column; lane 0 needs it for column 0)
-    if (tid >= 256 && tid - 256 < TH) snxl[tid - 256] = norm(*S(tid - 256, 0), *S(tid - 256, -2), *S(tid - 256, -1));
-    // ---- every wave takes the rows around its band into registers before any wave writes
-    const double2_t um2_0 = *reinterpret_cast<const double2_t *>(S(rb0 - 2, ca));
-    double2_t um = *reinterpret_cast<const double2_t *>(S(rb0 - 1, ca));
-    double2_t u0 = *reinterpret_cast<const double2_t *>(S(rb0, ca));
-    const double2_t ubot = *reinterpret_cast<const double2_t *>(S(rb1, ca));
-    double uw = *S(rb0, ca - 1), ue = *S(rb0, ca + 2);
-    const double2_t u1st = *reinterpret_cast<const double2_t *>(S(rb0 + 1 < rb1 ? rb0 + 1 : rb0, ca));   // row rb0 + 1 (own band, if it has one)
+    // (what an iteration needs that does NOT depend on the region means -- column -1's normalised x-gradient, the rows around the band in
+    // registers, ny of the row above the band -- was taken BEFORE the release was waited for: pre_reads, at the end of the previous iteration)
+    if (it == 0) pre_reads();
+    double2_t um = p_um, u0 = p_u0;
+    const double2_t ubot = p_ubot;
+    double uw = p_uw, ue = p_ue;
     lds_barrier();                                             // (LDS only: the master's bookkeeping stores may still be in flight)
     stamp(it, kStampIt, 1);                                    // table in LDS, band borders in registers
 
@@ -289,11 +308,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = 0;
     if (rb1 > rb0) {
-      double nypa = norm(u0.x, um2_0.x, um.x), nypb = norm(u0.y, um2_0.y, um.y);   // ny at row rb0 - 1
-      if (r0 + rb0 == 0) {   // kappa_y(0, .) = 0 (:372): ny_prev := row 0's own ny, the very expression the row uses
-        const double2_t up0 = (rb0 + 1 < rb1) ? u1st : ubot;
-        nypa = norm(up0.x, um.x, u0.x); nypb = norm(up0.y, um.y, u0.y);
-      }
+      double nypa = p_nypa, nypb = p_nypb;                      // ny at row rb0 - 1 (pre_reads)
       auto pixel = [&](double c, double n_, double s_, double nx, double nxl, double fx, double &nyp, int byte, double &ud_out,
                        double &Ik_out) -> double {
         const double ny = norm(s_, n_, c);
@@ -545,7 +560,8 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
         __syncthreads();
         if (!okn) { gave_up = true; break; }
         for (int p = tid; p < kPairs; p += RT_THREADS) fetch(p);
-        // (the barrier at the top of the next iteration orders these LDS writes before their readers)
+        lds_barrier();       // (the halo ring is complete)
+        pre_reads();
       }
     } else {
       // ---- workgroup 0 is the barrier's MASTER, and a tile like any other -- among the last to arrive as often as any other, so nothing of
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(RT_THREADS, 1) void csv_resident_kernel(const CvhSt
       lds_barrier();
       if (!okn || go_known < 0) { gave_up = true; break; }   // (a neighbour or the master's own collection gave up: the error word is up)
       if (book_pending) { book(c1, c2, book_nrm, 0, false); book_pending = false; }   // (c1 / c2: still the means this iteration ran with)
-      if (want_borders) { c1 = k1; c2 = k2; }
+      if (want_borders) { c1 = k1; c2 = k2; pre_reads(); }     // (the workers' fetch lies in front of the meeting's first barrier)
       have_go = true;
     }
   }
