@@ -37,6 +37,7 @@ struct cvh_context {
   int co_resident = 1;          // option "co_resident": 0 = a scratch / warm-up context that does not stream beside the others
   mutable int run_pol = -1;     // the decision of the current run (-1: not taken yet)
   mutable int run_alone = -1;   // 1: no other co-resident context on the device when the run started (automatic resident flow allowed)
+  int run_chunk = -1;           // iterations of the enqueue at hand (cvh_enqueue_steps / cvh_warm: their argument; cvh_run: its chunk) -- how long a cooperative launch would be (-1: nothing announced yet)
   CvhState *d_state = nullptr;
   CvhState *h_state = nullptr;  // pinned, four slots for pipelined polling
   double *d_partials = nullptr;
@@ -614,7 +615,7 @@ static int reset_run_impl(cvh_context *c)
   c->chain_pb = (c->chain_pb + c->steps_done) & 3;
   c->steps_done = 0;
   c->enqueued = 0;
-  c->run_pol = -1; c->run_alone = -1;          // the automatic choices of a run are taken again (live-context registry)
+  c->run_pol = -1; c->run_alone = -1; c->run_chunk = -1;   // the automatic choices of a run are taken again (live-context registry)
   static const int zeros[4] = {0, 0, 0, 0};   // steps_done, stopped, ticket, pending
   HIPCHK(c, hipMemcpyAsync(&c->d_state->steps_done, zeros, sizeof(zeros), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(&c->d_chain->v[(c->chain_pb + 1) & 3][0], 0, sizeof(c->d_chain->v[0]), c->stream));
@@ -815,7 +816,19 @@ static bool resident_geometry(cvh_context *c, ResidentGeom *rg)
   // ~25 us each, while interleaved per-launch flows fill each other's gaps -- measured, eight images interleaved in chunks of 8 iterations
   // (tools/batch_probe.py, gpurun_out/r4s9): 2048^2 32.6 us per image-iteration resident vs 16.2 per launch (17.3 with chunks of 50);
   // 1024^2 22.3 vs 6.1 (10.6).  Decided when a run's first iteration is enqueued, kept for the run.
-  if (c->resident_opt < 0 && !run_is_alone(c)) return false;
+  // End of round 4, with the resident kernel a quarter faster (12.1 us per iteration at 2048^2): a batch of LARGE planes whose runs are enqueued in
+  // LONG chunks is better off with one cooperative launch after the other -- eight planes, us per image-iteration, per-launch interleaved vs
+  // resident in chunks of 50 / 100 / 400 (gpurun_out/r4s61, r4s62): 2048^2 16.2 vs 14.7 / 13.2 / 12.1; 1792^2 13.4 vs 13.8 / 12.5 / 11.6;
+  // 1536^2 11.0 vs 12.2 / 10.8 / 9.9; 1280^2 8.2 vs 10.5 / 9.2 / 8.3; 1024^2 5.9 vs 8.2 / 6.9 / 6.1.  So in a batch an ENQUEUE takes the resident flow
+  // when it is long enough for the plane's size (cvh_run: chunks of up to 1024 iterations) -- per enqueue, not per run: a long warm-up chunk
+  // followed by chunks of 8 must not leave a run with 8-iteration cooperative launches (29 us per image-iteration at 2048^2).  The two flows
+  // continue each other on one context (sum sets, stop rule, trace); their level sets agree to <= 1e-9, not bit for bit -- a caller who needs
+  // the same bits whatever the chunking sets "resident" itself.
+  if (c->resident_opt < 0 && !run_is_alone(c)) {
+    const double px = (double)c->h * (double)c->w;
+    const int need = px >= 3.6e6 ? 48 : px >= 2.9e6 ? 72 : px >= 2.2e6 ? 100 : INT_MAX;
+    if (c->run_chunk < need) return false;
+  }
   if (c->resident_cap < 0) {
     int coop = 0;
     c->resident_cap = 0;
@@ -1174,6 +1187,7 @@ static int ensure_step_graph(cvh_context *c, int parity)
 // cvh_last_run_ms nor a caller's wall clock around cvh_enqueue_steps / cvh_sync is charged with it.
 static int warm_impl(cvh_context *c, long nsteps)
 {
+  if (nsteps > 0) c->run_chunk = (int)(nsteps < 1024 ? nsteps : 1024);   // (the caller announces its next enqueue)
   { ResidentGeom rg; if (resident_geometry(c, &rg)) return CVH_OK; }   // one cooperative launch per chunk: nothing to capture
   const Geometry g = resolve_geometry(c);
   if (g.strip >= 2) { const int rc = upload_strip_bounds(c, g); if (rc != CVH_OK) return rc; }
@@ -1239,6 +1253,7 @@ static int launch_resident(cvh_context *c, const ResidentGeom &rg, int nsteps, C
 static int enqueue_impl(cvh_context *c, int nsteps)
 {
   if (c->state_bits == 32 && nsteps > 0) c->mirror_valid = false;
+  if (nsteps > 0) c->run_chunk = nsteps;        // (resident_geometry's rule for a batch looks at the length of THIS enqueue)
   {
     ResidentGeom rg;
     if (resident_geometry(c, &rg)) return launch_resident(c, rg, nsteps, nullptr);
@@ -1369,7 +1384,8 @@ extern "C" int cvh_run(cvh_context *c, int max_steps, int *steps_done, double *l
   // resident mode: a chunk is ONE launch that loads the tiles, iterates and stores them; the stop rule ends it inside the kernel at the
   // reference's iteration, so chunks can be long (the tile load / store of a 2048^2 plane is worth ~0.4 us per iteration at 32)
   int chunk_len = c->sync_every;
-  { ResidentGeom rg; if (resident_geometry(c, &rg) && chunk_len < 1024) chunk_len = 1024; }
+  c->run_chunk = (int)(remaining < 1024 ? remaining : 1024);     // (what a chunk is if the run takes the resident flow: resident_geometry's rule for a batch)
+  { ResidentGeom rg; if (resident_geometry(c, &rg) && chunk_len < 1024) chunk_len = 1024; else c->run_chunk = chunk_len; }
   while (remaining > 0 && !stopped) {
     while (queued - hs[0] > kAhead * chunk_len && !hs[1]) {
       if (hipStreamQuery(c->stream) == hipSuccess) break;  // everything queued has run

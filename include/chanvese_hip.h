@@ -102,9 +102,13 @@ int cvh_set_params(cvh_context *ctx, const cvh_params *p);
  *                    at most one 128 x 128 tile per CU: up to 2048 x 2048 on an MI355X) iterate IN LDS -- one cooperative launch per
  *                    chunk of iterations, one workgroup per tile, a grid barrier per iteration, the stop rule inside the kernel at the
  *                    reference's iteration (csv_resident_kernel.hip).  Auto steps aside when "kernel", "strip_rows", "strips" or
- *                    "graph" were set (the caller asked for a per-launch flow), when "state" is 32, and when other co-resident
- *                    contexts live on the device (a batch: cooperative launches of different contexts serialise; interleaved
- *                    per-launch flows are twice as fast there)
+ *                    "graph" were set (the caller asked for a per-launch flow), when "state" is 32, and -- enqueue by enqueue -- when
+ *                    other co-resident contexts live on the device (a batch: cooperative launches of different contexts serialise, and
+ *                    interleaved per-launch flows are twice as fast in short chunks) UNLESS the plane is large and the enqueue long:
+ *                    from 48 iterations at >= 3.6 Mpixel, 72 at >= 2.9, 100 at >= 2.2 (cvh_run: chunks of up to 1024) one cooperative
+ *                    launch after the other wins (eight 2048 x 2048 planes: 12.1-14.7 against 16.2 us per image-iteration).  The two
+ *                    flows continue each other on one context and agree to 1e-9, not bit for bit: set 0 or 1 for the same bits
+ *                    whatever the chunking
  *   "wave_pol"       cache policy of the streamed level-set rows: -1 auto (write-through stores while the ping-pong pairs and planes of
  *                    ALL contexts on the device that hold an image and a level set fit the Infinity Cache, <= 300 MB together; decided
  *                    when a run's first iteration is enqueued, kept for the run), 0 plain, 1 write-through

@@ -177,6 +177,42 @@ def test_resident_release_lines_shared_or_not_same_results(capi, shape):
             ctx.set_option("res_go_share", 7)
 
 
+def test_a_batch_of_large_planes_in_long_chunks_takes_the_resident_flow(capi):
+    """End of round 4: in a batch (other co-resident contexts on the device) an enqueue still takes the resident flow when the plane is large and
+    the enqueue is long -- one cooperative launch after the other then beats interleaved per-launch flows (tools/batch_probe.py: eight 1536^2
+    planes 10.8 vs 11.0 us per image-iteration in chunks of 100, 2048^2 13.2 vs 16.2).  Short enqueues and smaller planes keep the per-launch
+    flow; the choice is taken per enqueue (a long warm-up chunk must not leave a run with 8-iteration cooperative launches); the two flows
+    continue each other on one context and agree to 1e-9."""
+    n = 1536
+    imgs = [synth.disk(n, 200, 50, noise=10, seed=s) for s in (21, 22)]
+    with capi.Context(n, n, 1, capi.make_params(tol=0)) as alone:
+        alone.set_image([imgs[0]]); alone.init_checkerboard()
+        alone.enqueue_steps(120); alone.enqueue_steps(8); alone.sync()
+        assert alone.launch_info()["kernel"].startswith("csv_resident_kernel<")
+        ref = alone.get_levelset()
+    a = capi.Context(n, n, 1, capi.make_params(tol=0)); b = capi.Context(n, n, 1, capi.make_params(tol=0))
+    try:
+        a.set_image([imgs[0]]); a.init_checkerboard()
+        b.set_image([imgs[1]]); b.init_checkerboard()
+        assert a.launch_info()["kernel"].startswith("csv_wave")            # a batch, nothing announced yet: the per-launch flow is what would run
+        a.enqueue_steps(120)                                               # long enqueue, large plane: resident
+        assert a.launch_info()["kernel"].startswith("csv_resident_kernel<")
+        b.enqueue_steps(8)                                                 # short enqueue: per launch
+        assert b.launch_info()["kernel"].startswith("csv_wave")
+        a.enqueue_steps(8); b.enqueue_steps(120)                           # per enqueue, not per run
+        assert a.launch_info()["kernel"].startswith("csv_wave") and b.launch_info()["kernel"].startswith("csv_resident_kernel<")
+        assert a.sync()[0] == 128 and b.sync()[0] == 128
+        assert rel_err(a.get_levelset(), ref) <= 1e-9                      # 120 resident + 8 per launch against 128 resident
+        assert b.run(150)[0] == 150                                        # cvh_run: its chunks are long
+        assert b.launch_info()["kernel"].startswith("csv_resident_kernel<")
+    finally:
+        a.close(); b.close()
+    with capi.Context(1024, 1024, 1, capi.make_params(tol=0)) as c1, capi.Context(1024, 1024, 1, capi.make_params(tol=0)) as c2:
+        for c in (c1, c2): c.set_image([synth.disk(1024, 200, 50, noise=10, seed=3)]); c.init_checkerboard()
+        c1.enqueue_steps(400); c1.sync()
+        assert c1.launch_info()["kernel"].startswith("csv_wave")           # 1024^2 in a batch: never resident by itself
+
+
 def test_priority_by_quarters_is_scheduling_only(capi):
     """Option "res_prio" (both resident kernels: a wave lowers its s_setprio level with every quarter of its band) changes WHEN a wave runs, never what
     it computes: level set, trace and the smoothed plane are the same bits with and without."""

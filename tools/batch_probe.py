@@ -7,7 +7,8 @@ import numpy as np
 from chan_vese_amd import capi, synth
 n = int(os.environ.get("N", "2048")); images = int(os.environ.get("IMAGES", "8")); steps = int(os.environ.get("STEPS", "400"))
 chunk = int(os.environ.get("CHUNK", "8")); reps = int(os.environ.get("REPS", "3"))
-for label, opts in (("auto", {}), ("resident=0", {"resident": 0}), ("resident=1, chunks of 50", {"resident": 1, "_chunk": 50}), ("auto, chunks of 50", {"_chunk": 50})):
+for label, opts in (("auto", {}), ("resident=0", {"resident": 0}), ("resident=1, chunks of 50", {"resident": 1, "_chunk": 50}), ("auto, chunks of 50", {"_chunk": 50}),
+                    ("resident=1, chunks of 100", {"resident": 1, "_chunk": 100}), ("resident=1, chunks of 400", {"resident": 1, "_chunk": 400}), ("resident=0, chunks of 400", {"resident": 0, "_chunk": 400})):
     ck = opts.pop("_chunk", chunk)
     ctxs = []
     for b in range(images):
